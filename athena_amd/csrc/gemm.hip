@@ -1,0 +1,243 @@
+// Dense-layer and Conv2D entry points on top of the shared GEMM cores.
+#include "gemm_core.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void athena_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* athena_last_error(void) { return g_err; }
+extern "C" int athena_abi_version(void) { return 1; }
+
+static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
+    memset(&e, 0, sizeof(e));
+    e.C = d->C;
+    e.C_pre = d->C_pre;
+    e.bias = d->bias;
+    e.aux = d->aux;
+    e.rng_state = d->rng_state;
+    e.colsum = nullptr;
+    e.ldc = d->ldc;
+    e.ldaux = d->ldaux;
+    e.c_dtype = d->out_dtype;
+    e.aux_dtype = d->aux_dtype;
+    e.act = d->act;
+    e.atomic = d->split_k > 1;
+    e.accum = d->accumulate;
+    e.alpha = d->alpha;
+    e.drop_thresh = d->drop_p > 0.f ? dropout_threshold(d->drop_p) : 0u;
+    e.drop_scale = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+    e.rng_site = d->rng_site;
+}
+
+extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
+    ATHENA_REQUIRE(d && d->A && d->B && d->C, ATHENA_E_SHAPE, "athena_gemm: null operand");
+    ATHENA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, ATHENA_E_SHAPE, "athena_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    ATHENA_REQUIRE(d->split_k >= 0 && d->split_k <= 1024, ATHENA_E_SHAPE, "athena_gemm: bad split_k %d", d->split_k);
+    ATHENA_REQUIRE(d->in_dtype == ATHENA_F32 || d->in_dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "athena_gemm: in_dtype");
+    ATHENA_REQUIRE(d->out_dtype == ATHENA_F32 || d->out_dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "athena_gemm: out_dtype");
+    const int a_cols = d->trans_a ? d->M : d->K;
+    const int b_cols = d->trans_b ? d->K : d->N;
+    ATHENA_REQUIRE(d->lda >= a_cols && d->ldb >= b_cols && d->ldc >= d->N, ATHENA_E_SHAPE,
+                   "athena_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", d->lda, d->ldb, d->ldc);
+    int split = d->split_k;
+    if (split == 0) split = gemm_auto_split(d->M, d->N, d->K, d->in_dtype);
+    if (d->split_k != 1)
+        ATHENA_REQUIRE(d->out_dtype == ATHENA_F32 && d->act == ATHENA_ACT_NONE && !d->bias && !d->C_pre &&
+                           d->drop_p == 0.f && !d->accumulate,
+                       ATHENA_E_UNSUPPORTED, "athena_gemm: split_k needs a plain fp32 output");
+    if (d->act == ATHENA_ACT_MUL_DGELU || d->act == ATHENA_ACT_MUL_DRELU6)
+        ATHENA_REQUIRE(d->aux && d->ldaux >= d->N, ATHENA_E_SHAPE, "athena_gemm: backward epilogue needs aux");
+    if (d->drop_p > 0.f)
+        ATHENA_REQUIRE(d->rng_state && d->drop_p < 1.f, ATHENA_E_SHAPE, "athena_gemm: dropout needs rng_state and p < 1");
+    if (d->in_dtype == ATHENA_BF16) {
+        ATHENA_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, ATHENA_E_ALIGN,
+                       "athena_gemm: bf16 needs lda, ldb multiples of 8 (lda=%d ldb=%d)", d->lda, d->ldb);
+        ATHENA_REQUIRE((d->trans_a && !d->trans_b) || d->K % 8 == 0, ATHENA_E_ALIGN,
+                       "athena_gemm: bf16 needs K %% 8 == 0 unless trans_a && !trans_b (K=%d)", d->K);
+        ATHENA_REQUIRE(!d->trans_a || d->lda >= (d->M + 7) / 8 * 8, ATHENA_E_ALIGN, "athena_gemm: trans_a needs lda >= roundup8(M) (M=%d lda=%d)", d->M, d->lda);
+        ATHENA_REQUIRE(d->trans_b || d->ldb >= (d->N + 7) / 8 * 8, ATHENA_E_ALIGN, "athena_gemm: !trans_b needs ldb >= roundup8(N) (N=%d ldb=%d)", d->N, d->ldb);
+        ATHENA_REQUIRE(athena_aligned16(d->A) && athena_aligned16(d->B), ATHENA_E_ALIGN, "athena_gemm: operands must be 16-byte aligned");
+    }
+    GemmProblem<PlainRows> p;
+    memset(&p, 0, sizeof(p));
+    p.A = d->A;
+    p.B = d->B;
+    p.amap.ld = d->lda;
+    p.amap.seg_stride = 0;
+    p.M = d->M;
+    p.N = d->N;
+    p.nseg = 1;
+    p.kseg = d->K;
+    p.ldb = d->ldb;
+    p.seg_base = 0;
+    p.split_k = split;
+    fill_epilogue(p.epi, d);
+    p.epi.atomic = split > 1;
+    if (d->split_k == 0 && split > 1) {
+        // auto split: the library zero-fills the fp32 output it is about to accumulate into
+        hipError_t e = (d->ldc == d->N)
+                           ? hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, (hipStream_t)stream)
+                           : hipMemset2DAsync(d->C, sizeof(float) * (size_t)d->ldc, 0, sizeof(float) * (size_t)d->N, d->M, (hipStream_t)stream);
+        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
+    }
+    p.crow_mode = 0;
+    return launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ Conv2D 3x3 / stride 2 / same
+static inline void same_pad(int n, int* out, int* pad_before) {
+    int o = (n + 1) / 2;
+    int total = (o - 1) * 2 + 3 - n;
+    if (total < 0) total = 0;
+    *out = o;
+    *pad_before = total / 2;
+}
+
+static int conv_check(const char* name, int B, int H, int W, int Cin, int Cout, int dtype) {
+    ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, ATHENA_E_SHAPE, "%s: bad shape", name);
+    ATHENA_REQUIRE(dtype == ATHENA_F32 || dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "%s: dtype", name);
+    if (dtype == ATHENA_BF16)
+        ATHENA_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0, ATHENA_E_ALIGN, "%s: bf16 needs Cin, Cout multiples of 8", name);
+    ATHENA_REQUIRE((long)B * H * W < (1L << 31) / 4, ATHENA_E_SHAPE, "%s: too many pixels", name);
+    return ATHENA_OK;
+}
+
+extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout, void* out, int B, int H, int W,
+                                    int Cin, int Cout, int dtype, double* colstats, athena_stream_t stream) {
+    int rc = conv_check("athena_conv3x3s2_fwd", B, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(in && w && out, ATHENA_E_SHAPE, "athena_conv3x3s2_fwd: null operand");
+    int Ho, Wo, ph, pw;
+    same_pad(H, &Ho, &ph);
+    same_pad(W, &Wo, &pw);
+    GemmProblem<ConvFwdRows> p;
+    memset(&p, 0, sizeof(p));
+    p.A = in;
+    p.B = w;
+    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
+    p.M = B * Ho * Wo;
+    p.N = Cout;
+    p.nseg = 9;
+    p.kseg = Cin;
+    p.seg_base = 0;
+    p.split_k = 1;
+    if (w_layout == 1) {   // [Cout][9][Cin]
+        p.ldb = 9L * Cin;
+        for (int s = 0; s < 9; ++s) p.b_seg_off[s] = (long)s * Cin;
+    } else {               // HWIO [9][Cin][Cout]
+        p.ldb = Cout;
+        for (int s = 0; s < 9; ++s) p.b_seg_off[s] = (long)s * Cin * Cout;
+    }
+    p.epi.C = out;
+    p.epi.ldc = Cout;
+    p.epi.c_dtype = dtype;
+    p.epi.alpha = 1.f;
+    p.epi.colsum = colstats;
+    if (colstats) {
+        hipError_t e = hipMemsetAsync(colstats, 0, sizeof(double) * 2 * Cout, (hipStream_t)stream);
+        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_fwd: memset failed");
+    }
+    return launch_gemm(p, dtype, false, w_layout == 1, (hipStream_t)stream);
+}
+
+extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void* din, int B, int H, int W, int Cin,
+                                      int Cout, int dtype, athena_stream_t stream) {
+    int rc = conv_check("athena_conv3x3s2_dgrad", B, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(dout && w_hwio && din, ATHENA_E_SHAPE, "athena_conv3x3s2_dgrad: null operand");
+    int Ho, Wo, ph, pw;
+    same_pad(H, &Ho, &ph);
+    same_pad(W, &Wo, &pw);
+    // padded coordinate hp = h + pad: even hp = 2a is reached by taps kh=0 (ho=a) and kh=2 (ho=a-1),
+    // odd hp = 2a+1 by tap kh=1 (ho=a)
+    for (int ch = 0; ch < 2; ++ch) {
+        for (int cw = 0; cw < 2; ++cw) {
+            // first pixel of the class and its 'a'
+            int h0 = ((ch - ph) % 2 + 2) % 2;            // smallest h >= 0 with (h + ph) % 2 == ch
+            int w0 = ((cw - pw) % 2 + 2) % 2;
+            if (h0 >= H || w0 >= W) continue;
+            int a0h = (h0 + ph) / 2, a0w = (w0 + pw) / 2;
+            int Ah = (H - h0 + 1) / 2, Aw = (W - w0 + 1) / 2;
+            int khs[2], dhs[2], nh = 0, kws[2], dws[2], nw = 0;
+            if (ch == 0) { khs[0] = 0; dhs[0] = a0h; khs[1] = 2; dhs[1] = a0h - 1; nh = 2; }
+            else { khs[0] = 1; dhs[0] = a0h; nh = 1; }
+            if (cw == 0) { kws[0] = 0; dws[0] = a0w; kws[1] = 2; dws[1] = a0w - 1; nw = 2; }
+            else { kws[0] = 1; dws[0] = a0w; nw = 1; }
+            GemmProblem<ConvDgradRows> p;
+            memset(&p, 0, sizeof(p));
+            p.A = dout;
+            p.B = w_hwio;
+            p.amap.Ho = Ho; p.amap.Wo = Wo; p.amap.Co = Cout; p.amap.Ah = Ah; p.amap.Aw = Aw;
+            int s = 0;
+            for (int i = 0; i < nh; ++i)
+                for (int j = 0; j < nw; ++j) {
+                    p.amap.dh[s] = dhs[i];
+                    p.amap.dw[s] = dws[j];
+                    p.b_seg_off[s] = (long)(khs[i] * 3 + kws[j]) * Cin * Cout;
+                    ++s;
+                }
+            p.M = B * Ah * Aw;
+            p.N = Cin;
+            p.nseg = s;
+            p.kseg = Cout;
+            p.ldb = Cout;          // B(k = co, n = ci) = w[tap][ci][co]: "[N][K]" with ld = Cout
+            p.seg_base = 0;
+            p.split_k = 1;
+            p.epi.C = din;
+            p.epi.ldc = Cin;
+            p.epi.c_dtype = dtype;
+            p.epi.alpha = 1.f;
+            p.crow_mode = 1;
+            p.cr_Ah = Ah; p.cr_Aw = Aw; p.cr_H = H; p.cr_W = W; p.cr_h0 = h0; p.cr_w0 = w0;
+            rc = launch_gemm(p, dtype, false, true, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    }
+    return ATHENA_OK;
+}
+
+extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* dw_hwio, int B, int H, int W, int Cin,
+                                      int Cout, int dtype, athena_stream_t stream) {
+    int rc = conv_check("athena_conv3x3s2_wgrad", B, H, W, Cin, Cout, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(in && dout && dw_hwio, ATHENA_E_SHAPE, "athena_conv3x3s2_wgrad: null operand");
+    int Ho, Wo, ph, pw;
+    same_pad(H, &Ho, &ph);
+    same_pad(W, &Wo, &pw);
+    hipError_t e = hipMemsetAsync(dw_hwio, 0, sizeof(float) * 9L * Cin * Cout, (hipStream_t)stream);
+    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_wgrad: memset failed");
+    const int rows = B * Ho * Wo;
+    // dw[tap][ci][co] = sum_r in(r, tap)[ci] * dout[r][co]: A transposed through the gather, B = dout [K][N]
+    int split = gemm_auto_split(Cin, Cout, rows, dtype);
+    // nine launches share the chip
+    split = (split + 8) / 9;
+    if (split < 1) split = 1;
+    for (int tap = 0; tap < 9; ++tap) {
+        GemmProblem<ConvFwdRows> p;
+        memset(&p, 0, sizeof(p));
+        p.A = in;
+        p.B = dout;
+        p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
+        p.M = Cin;
+        p.N = Cout;
+        p.nseg = 1;
+        p.kseg = rows;
+        p.ldb = Cout;
+        p.seg_base = tap;
+        p.split_k = split;
+        p.epi.C = dw_hwio + (long)tap * Cin * Cout;
+        p.epi.ldc = Cout;
+        p.epi.c_dtype = ATHENA_F32;
+        p.epi.alpha = 1.f;
+        p.epi.atomic = 1;
+        rc = launch_gemm(p, dtype, true, false, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ATHENA_OK;
+}

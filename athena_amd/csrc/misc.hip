@@ -1,0 +1,396 @@
+// Front-end helpers: the few-input-channel 3x3/stride-2 convolution (the fbank input has one
+// channel), positional encoding + dropout, embedding gather/scatter, casts.
+#include "common.h"
+
+static inline void same_pad2(int n, int* out, int* pad_before) {
+    int o = (n + 1) / 2;
+    int total = (o - 1) * 2 + 3 - n;
+    if (total < 0) total = 0;
+    *out = o;
+    *pad_before = total / 2;
+}
+
+// ---------------------------------------------------------------- conv, small Cin, forward
+// thread = (pixel slot, 8 output channels); weights for the thread's channels live in registers
+// (9*Cin*8 floats, Cin <= 4 is looped outside to bound registers); per-channel statistics of the
+// stored values are reduced per workgroup and added with fp64 atomics.
+#define SC_PIX_PER_BLOCK 256
+template <typename T>
+__global__ __launch_bounds__(256) void conv_small_cin_fwd_kernel(const float* __restrict__ in,
+                                                                 const float* __restrict__ w, T* __restrict__ out,
+                                                                 int B, int H, int W, int Cin, int Cout, int Ho,
+                                                                 int Wo, int ph, int pw, double* __restrict__ stats) {
+    __shared__ float red[256][17];
+    const int cpr = Cout / 8;
+    const int cpb = min(cpr, 256);
+    const int slots = 256 / cpb;
+    const int chunk = blockIdx.y * cpb + (threadIdx.x % cpb);
+    const int slot = threadIdx.x / cpb;
+    const long npix = (long)B * Ho * Wo;
+    const long p0 = (long)blockIdx.x * SC_PIX_PER_BLOCK;
+    const long p1 = min(npix, p0 + SC_PIX_PER_BLOCK);
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (chunk < cpr && slot < slots) {
+        const int c0 = chunk * 8;
+        for (long pix = p0 + slot; pix < p1; pix += slots) {
+            const int wo = (int)(pix % Wo);
+            const long t = pix / Wo;
+            const int ho = (int)(t % Ho);
+            const int b = (int)(t / Ho);
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int kh = 0; kh < 3; ++kh) {
+                const int h = 2 * ho - ph + kh;
+                if (h < 0 || h >= H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int x = 2 * wo - pw + kw;
+                    if (x < 0 || x >= W) continue;
+                    const float* ip = in + (((long)b * H + h) * W + x) * Cin;
+                    const float* wp = w + ((long)(kh * 3 + kw) * Cin) * Cout + c0;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float iv = ip[ci];
+                        const float4 w0 = *(const float4*)(wp + (long)ci * Cout);
+                        const float4 w1 = *(const float4*)(wp + (long)ci * Cout + 4);
+                        acc[0] = fmaf(iv, w0.x, acc[0]); acc[1] = fmaf(iv, w0.y, acc[1]);
+                        acc[2] = fmaf(iv, w0.z, acc[2]); acc[3] = fmaf(iv, w0.w, acc[3]);
+                        acc[4] = fmaf(iv, w1.x, acc[4]); acc[5] = fmaf(iv, w1.y, acc[5]);
+                        acc[6] = fmaf(iv, w1.z, acc[6]); acc[7] = fmaf(iv, w1.w, acc[7]);
+                    }
+                }
+            }
+            T* op = out + pix * Cout + c0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                T st = from_f32<T>(acc[i]);
+                op[i] = st;
+                float sv = to_f32<T>(st);
+                s1[i] += sv;
+                s2[i] += sv * sv;
+            }
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = s1[i]; red[threadIdx.x][8 + i] = s2[i]; }
+    __syncthreads();
+    if (slot == 0 && chunk < cpr) {
+        const int c0 = chunk * 8;
+        for (int i = 0; i < 8; ++i) {
+            float a = 0.f, q = 0.f;
+            for (int k = 0; k < slots; ++k) {
+                a += red[k * cpb + (threadIdx.x % cpb)][i];
+                q += red[k * cpb + (threadIdx.x % cpb)][8 + i];
+            }
+            atomicAdd(stats + c0 + i, (double)a);
+            atomicAdd(stats + Cout + c0 + i, (double)q);
+        }
+    }
+}
+
+extern "C" int athena_conv3x3s2_small_cin_fwd(const float* in, const float* w_hwio, void* out, int B, int H, int W,
+                                              int Cin, int Cout, int dtype, double* colstats,
+                                              athena_stream_t stream) {
+    ATHENA_REQUIRE(in && w_hwio && out, ATHENA_E_SHAPE, "athena_conv3x3s2_small_cin_fwd: null operand");
+    ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 4 && Cout > 0 && Cout % 8 == 0, ATHENA_E_SHAPE,
+                   "athena_conv3x3s2_small_cin_fwd: needs Cin <= 4 and Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    int Ho, Wo, ph, pw;
+    same_pad2(H, &Ho, &ph);
+    same_pad2(W, &Wo, &pw);
+    hipStream_t s = (hipStream_t)stream;
+    if (colstats)
+        ATHENA_REQUIRE(hipMemsetAsync(colstats, 0, sizeof(double) * 2 * Cout, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_small_cin_fwd: memset failed");
+    const int cpr = Cout / 8, cpb = cpr < 256 ? cpr : 256;
+    const long npix = (long)B * Ho * Wo;
+    dim3 grid((unsigned)((npix + SC_PIX_PER_BLOCK - 1) / SC_PIX_PER_BLOCK), (cpr + cpb - 1) / cpb);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(conv_small_cin_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, in, w_hwio, (bf16_t*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(conv_small_cin_fwd_kernel<float>, grid, dim3(256), 0, s, in, w_hwio, (float*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_conv3x3s2_small_cin_fwd: dtype");
+    ATHENA_CHECK_LAUNCH("athena_conv3x3s2_small_cin_fwd");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- conv, small Cin, weight gradient
+// dw[tap][ci][co] = sum_pix in(pix, tap)[ci] * dout[pix][co]; one pass per ci (grid.z)
+#define SW_PIX_PER_BLOCK 1024
+template <typename T>
+__global__ __launch_bounds__(256) void conv_small_cin_wgrad_kernel(const float* __restrict__ in,
+                                                                   const T* __restrict__ dout,
+                                                                   float* __restrict__ dw, int B, int H, int W,
+                                                                   int Cin, int Cout, int Ho, int Wo, int ph, int pw) {
+    __shared__ float red[256][9];
+    const int ci = blockIdx.z;
+    const int cpr = Cout / 8;
+    const int cpb = min(cpr, 256);
+    const int slots = 256 / cpb;
+    const int chunk = blockIdx.y * cpb + (threadIdx.x % cpb);
+    const int slot = threadIdx.x / cpb;
+    const long npix = (long)B * Ho * Wo;
+    const long p0 = (long)blockIdx.x * SW_PIX_PER_BLOCK;
+    const long p1 = min(npix, p0 + SW_PIX_PER_BLOCK);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+    if (chunk < cpr && slot < slots) {
+        const int c0 = chunk * 8;
+        for (long pix = p0 + slot; pix < p1; pix += slots) {
+            const int wo = (int)(pix % Wo);
+            const long t = pix / Wo;
+            const int ho = (int)(t % Ho);
+            const int b = (int)(t / Ho);
+            float g[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = to_f32<T>(dout[pix * Cout + c0 + i]);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int h = 2 * ho - ph + kh;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int x = 2 * wo - pw + kw;
+                    float iv = 0.f;
+                    if (h >= 0 && h < H && x >= 0 && x < W) iv = in[(((long)b * H + h) * W + x) * Cin + ci];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[kh * 3 + kw][i] = fmaf(iv, g[i], acc[kh * 3 + kw][i]);
+                }
+            }
+        }
+    }
+    // reduce the row slots tap by tap
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[t][i];
+        __syncthreads();
+        if (slot == 0 && chunk < cpr) {
+            const int c0 = chunk * 8;
+            for (int i = 0; i < 8; ++i) {
+                float a = 0.f;
+                for (int k = 0; k < slots; ++k) a += red[k * cpb + (threadIdx.x % cpb)][i];
+                atomicAdd(dw + ((long)t * Cin + ci) * Cout + c0 + i, a);
+            }
+        }
+    }
+}
+
+extern "C" int athena_conv3x3s2_small_cin_wgrad(const float* in, const void* dout, float* dw_hwio, int B, int H,
+                                                int W, int Cin, int Cout, int dtype, athena_stream_t stream) {
+    ATHENA_REQUIRE(in && dout && dw_hwio, ATHENA_E_SHAPE, "athena_conv3x3s2_small_cin_wgrad: null operand");
+    ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 4 && Cout > 0 && Cout % 8 == 0, ATHENA_E_SHAPE,
+                   "athena_conv3x3s2_small_cin_wgrad: needs Cin <= 4 and Cout %% 8 == 0");
+    int Ho, Wo, ph, pw;
+    same_pad2(H, &Ho, &ph);
+    same_pad2(W, &Wo, &pw);
+    hipStream_t s = (hipStream_t)stream;
+    ATHENA_REQUIRE(hipMemsetAsync(dw_hwio, 0, sizeof(float) * 9L * Cin * Cout, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_small_cin_wgrad: memset failed");
+    const int cpr = Cout / 8, cpb = cpr < 256 ? cpr : 256;
+    const long npix = (long)B * Ho * Wo;
+    dim3 grid((unsigned)((npix + SW_PIX_PER_BLOCK - 1) / SW_PIX_PER_BLOCK), (cpr + cpb - 1) / cpb, Cin);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(conv_small_cin_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, in, (const bf16_t*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(conv_small_cin_wgrad_kernel<float>, grid, dim3(256), 0, s, in, (const float*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_conv3x3s2_small_cin_wgrad: dtype");
+    ATHENA_CHECK_LAUNCH("athena_conv3x3s2_small_cin_wgrad");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- positional encoding / dropout
+template <typename T>
+__global__ void add_pe_dropout_kernel(const T* __restrict__ x, const float* __restrict__ pe, long n, int Tn, int d,
+                                      float xscale, uint32_t thresh, float dscale, const uint64_t* rng_state,
+                                      uint32_t site, T* __restrict__ y) {
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const int t = (int)((i / d) % Tn);
+        float v = to_f32<T>(x[i]) * xscale + pe[(long)t * d + c];
+        if (thresh) v *= dropout_mult(key, (uint64_t)i, thresh, dscale);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+extern "C" int athena_add_pe_dropout(const void* x, const float* pe, int B, int T, int d, int dtype, float xscale,
+                                     float drop_p, const uint64_t* rng_state, uint32_t rng_site, void* y,
+                                     athena_stream_t stream) {
+    ATHENA_REQUIRE(x && pe && y && B > 0 && T > 0 && d > 0, ATHENA_E_SHAPE, "athena_add_pe_dropout: bad arguments");
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_add_pe_dropout: dropout args");
+    const long n = (long)B * T * d;
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(add_pe_dropout_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(add_pe_dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (float*)y);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_add_pe_dropout: dtype");
+    ATHENA_CHECK_LAUNCH("athena_add_pe_dropout");
+    return ATHENA_OK;
+}
+
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* __restrict__ dy, long n, float xscale, uint32_t thresh, float dscale,
+                                   const uint64_t* rng_state, uint32_t site, const T* __restrict__ relu6_out,
+                                   T* __restrict__ dx) {
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = to_f32<T>(dy[i]) * xscale;
+        if (thresh) v *= dropout_mult(key, (uint64_t)i, thresh, dscale);
+        if (relu6_out) {
+            const float y = to_f32<T>(relu6_out[i]);
+            if (!(y > 0.f && y < 6.f)) v = 0.f;
+        }
+        dx[i] = from_f32<T>(v);
+    }
+}
+
+extern "C" int athena_dropout_bwd(const void* dy, long n, int dtype, float xscale, float drop_p,
+                                  const uint64_t* rng_state, uint32_t rng_site, const void* relu6_out, void* dx,
+                                  athena_stream_t stream) {
+    ATHENA_REQUIRE(dy && dx && n > 0, ATHENA_E_SHAPE, "athena_dropout_bwd: bad arguments");
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_dropout_bwd: dropout args");
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, n, xscale, th, ds, rng_state, rng_site, (const bf16_t*)relu6_out, (bf16_t*)dx);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, n, xscale, th, ds, rng_state, rng_site, (const float*)relu6_out, (float*)dx);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_dropout_bwd: dtype");
+    ATHENA_CHECK_LAUNCH("athena_dropout_bwd");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- embedding
+template <typename T>
+__global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                 const float* __restrict__ pe, long n, int L, int d, int V, float xscale,
+                                 uint32_t thresh, float dscale, const uint64_t* rng_state, uint32_t site,
+                                 T* __restrict__ y) {
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const long tok = i / d;
+        const int l = (int)(tok % L);
+        int id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        float v = table[(long)id * d + c] * xscale + pe[(long)l * d + c];
+        if (thresh) v *= dropout_mult(key, (uint64_t)i, thresh, dscale);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void embed_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids, long n, int d, int V,
+                                 float xscale, uint32_t thresh, float dscale, const uint64_t* rng_state,
+                                 uint32_t site, float* __restrict__ dtable) {
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % d);
+        const long tok = i / d;
+        int id = ids[tok];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        float v = to_f32<T>(dy[i]) * xscale;
+        if (thresh) v *= dropout_mult(key, (uint64_t)i, thresh, dscale);
+        atomicAdd(dtable + (long)id * d + c, v);
+    }
+}
+
+extern "C" int athena_embed_fwd(const float* table, const int32_t* ids, const float* pe, int B, int L, int d, int V,
+                                int dtype, float xscale, float drop_p, const uint64_t* rng_state, uint32_t rng_site,
+                                void* y, athena_stream_t stream) {
+    ATHENA_REQUIRE(table && ids && pe && y && B > 0 && L > 0 && d > 0 && V > 0, ATHENA_E_SHAPE, "athena_embed_fwd: bad arguments");
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_embed_fwd: dropout args");
+    const long n = (long)B * L * d;
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (float*)y);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_fwd: dtype");
+    ATHENA_CHECK_LAUNCH("athena_embed_fwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L, int d, int V, int dtype,
+                                float xscale, float drop_p, const uint64_t* rng_state, uint32_t rng_site,
+                                float* dtable, athena_stream_t stream) {
+    ATHENA_REQUIRE(dy && ids && dtable && B > 0 && L > 0 && d > 0 && V > 0, ATHENA_E_SHAPE, "athena_embed_bwd: bad arguments");
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_embed_bwd: dropout args");
+    const long n = (long)B * L * d;
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_bwd: dtype");
+    ATHENA_CHECK_LAUNCH("athena_embed_bwd");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- casts / axpby
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+
+extern "C" int athena_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, athena_stream_t stream) {
+    ATHENA_REQUIRE(src && dst && n > 0, ATHENA_E_SHAPE, "athena_cast: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((unsigned)blocks), b(256);
+    if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_cast: dtype");
+    ATHENA_CHECK_LAUNCH("athena_cast");
+    return ATHENA_OK;
+}
+
+template <typename T>
+__global__ void axpby_kernel(float a, const T* __restrict__ x, float b, T* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = a * to_f32<T>(x[i]);
+        if (b != 0.f) v += b * to_f32<T>(y[i]);
+        y[i] = from_f32<T>(v);
+    }
+}
+
+extern "C" int athena_axpby(float a, const void* x, float b, void* y, long n, int dtype, athena_stream_t stream) {
+    ATHENA_REQUIRE(x && y && n > 0, ATHENA_E_SHAPE, "athena_axpby: bad arguments");
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16) hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const bf16_t*)x, b, (bf16_t*)y, n);
+    else if (dtype == ATHENA_F32) hipLaunchKernelGGL(axpby_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)x, b, (float*)y, n);
+    else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_axpby: dtype");
+    ATHENA_CHECK_LAUNCH("athena_axpby");
+    return ATHENA_OK;
+}

@@ -1,0 +1,472 @@
+// LayerNormalization (with fused residual add + dropout), BatchNormalization + relu6,
+// column sums.  All arithmetic in fp32 (fp64 for the batch statistics).
+#include "common.h"
+
+// ---------------------------------------------------------------- 8-wide vector access
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        bf16x8_t a = *(const bf16x8_t*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        bf16x8_t a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+        *(bf16x8_t*)p = a;
+    }
+};
+
+// ================================================================ LayerNorm
+// one wave per row, 4 rows per 256-thread block
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, int rows,
+                                                                int d, uint32_t thresh, float dscale,
+                                                                const uint64_t* rng_state, uint32_t site,
+                                                                T* __restrict__ z, T* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    const long base = (long)row * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float v = to_f32<T>(a[base + c]);
+        if (b) {
+            float bv = to_f32<T>(b[base + c]);
+            if (thresh) bv *= dropout_mult(key, (uint64_t)(base + c), thresh, dscale);
+            v += bv;
+        }
+        // the stored z is what the backward pass reads; round-trip it so both passes see one value
+        T zt = from_f32<T>(v);
+        z[base + c] = zt;
+        s += to_f32<T>(zt);
+    }
+    s = wave_sum(s);
+    const float mu = s / d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        float dv = to_f32<T>(z[base + c]) - mu;
+        q += dv * dv;
+    }
+    q = wave_sum(q);
+    const float rs = rsqrtf(q / d + eps);
+    for (int c = lane; c < d; c += 64) {
+        float xh = (to_f32<T>(z[base + c]) - mu) * rs;
+        y[base + c] = from_f32<T>(xh * gamma[c] + beta[c]);
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// block = 256 threads = 4 waves; each wave walks rows r = blockIdx*ROWS_PER_BLOCK + w, +4, ...
+// per-lane register partials of dgamma/dbeta for columns lane + 64*v, v < VPL
+#define LN_ROWS_PER_BLOCK 32
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, int rows, int d,
+                                                                uint32_t thresh, float dscale,
+                                                                const uint64_t* rng_state, uint32_t site,
+                                                                int accumulate_da, T* __restrict__ da,
+                                                                T* __restrict__ db, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+    __shared__ float red[4][64 * VPL];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    float g[VPL], pg[VPL], pb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        int c = lane + 64 * v;
+        g[v] = c < d ? gamma[c] : 0.f;
+        pg[v] = 0.f;
+        pb[v] = 0.f;
+    }
+    const int r0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+    const int r1 = min(rows, r0 + LN_ROWS_PER_BLOCK);
+    for (int row = r0 + w; row < r1; row += 4) {
+        const long base = (long)row * d;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[VPL], gy[VPL];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            int c = lane + 64 * v;
+            float dyv = 0.f, x = 0.f;
+            if (c < d) {
+                dyv = to_f32<T>(dy[base + c]);
+                x = (to_f32<T>(z[base + c]) - mu) * rs;
+            }
+            xh[v] = x;
+            gy[v] = dyv * g[v];
+            pg[v] += dyv * x;
+            pb[v] += dyv;
+            c1 += gy[v];
+            c2 += gy[v] * x;
+        }
+        c1 = wave_sum(c1) / d;
+        c2 = wave_sum(c2) / d;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            int c = lane + 64 * v;
+            if (c < d) {
+                float dz = rs * (gy[v] - c1 - xh[v] * c2);
+                float dav = dz;
+                if (accumulate_da) dav += to_f32<T>(da[base + c]);
+                da[base + c] = from_f32<T>(dav);
+                if (db) {
+                    float m = thresh ? dropout_mult(key, (uint64_t)(base + c), thresh, dscale) : 1.f;
+                    db[base + c] = from_f32<T>(dz * m);
+                }
+            }
+        }
+    }
+    // fold the 4 waves, one atomic per column per block
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) red[w][lane + 64 * v] = pg[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dgamma + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) red[w][lane + 64 * v] = pb[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dbeta + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta,
+                                        float eps, int rows, int d, int dtype, float drop_p,
+                                        const uint64_t* rng_state, uint32_t rng_site, void* z, void* y,
+                                        float* mean, float* rstd, athena_stream_t stream) {
+    ATHENA_REQUIRE(a && gamma && beta && z && y && mean && rstd, ATHENA_E_SHAPE, "add_layernorm_fwd: null operand");
+    ATHENA_REQUIRE(rows > 0 && d > 0, ATHENA_E_SHAPE, "add_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && b), ATHENA_E_SHAPE, "add_layernorm_fwd: dropout args");
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    dim3 grid((rows + 3) / 4);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+                           (const bf16_t*)b, gamma, beta, eps, rows, d, th, ds, rng_state, rng_site, (bf16_t*)z,
+                           (bf16_t*)y, mean, rstd);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(add_layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                           (const float*)b, gamma, beta, eps, rows, d, th, ds, rng_state, rng_site, (float*)z,
+                           (float*)y, mean, rstd);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "add_layernorm_fwd: dtype");
+    ATHENA_CHECK_LAUNCH("add_layernorm_fwd");
+    return ATHENA_OK;
+}
+
+template <typename T>
+static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
+                         int rows, int d, uint32_t th, float ds, const uint64_t* rng_state, uint32_t site,
+                         int acc, void* da, void* db, float* dgamma, float* dbeta, hipStream_t stream) {
+    dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK);
+#define LN_BWD_CASE(V)                                                                                          \
+    hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, V>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)z, \
+                       mean, rstd, gamma, rows, d, th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, dbeta)
+    if (d <= 64 * 4) LN_BWD_CASE(4);
+    else if (d <= 64 * 8) LN_BWD_CASE(8);
+    else if (d <= 64 * 16) LN_BWD_CASE(16);
+    else LN_BWD_CASE(32);
+#undef LN_BWD_CASE
+    ATHENA_CHECK_LAUNCH("add_layernorm_bwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_add_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
+                                        const float* gamma, int rows, int d, int dtype, float drop_p,
+                                        const uint64_t* rng_state, uint32_t rng_site, int accumulate_da, void* da,
+                                        void* db, float* dgamma, float* dbeta, athena_stream_t stream) {
+    ATHENA_REQUIRE(dy && z && mean && rstd && gamma && da && dgamma && dbeta, ATHENA_E_SHAPE, "add_layernorm_bwd: null operand");
+    ATHENA_REQUIRE(rows > 0 && d > 0 && d <= 2048, ATHENA_E_SHAPE, "add_layernorm_bwd: bad shape rows=%d d=%d (d <= 2048)", rows, d);
+    ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && db), ATHENA_E_SHAPE, "add_layernorm_bwd: dropout args");
+    uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
+    float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    hipStream_t s = (hipStream_t)stream;
+    ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, s) == hipSuccess &&
+                       hipMemsetAsync(dbeta, 0, sizeof(float) * d, s) == hipSuccess,
+                   ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
+    if (dtype == ATHENA_BF16)
+        return launch_ln_bwd<bf16_t>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, s);
+    if (dtype == ATHENA_F32)
+        return launch_ln_bwd<float>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, s);
+    ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "add_layernorm_bwd: dtype");
+}
+
+// ================================================================ column sums (bias gradients)
+// threads are laid out as (row slot, 8-column chunk); a thread always owns the same chunk.
+#define CS_ROWS_PER_BLOCK 256
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int M, int N, int ld,
+                                                     float* __restrict__ out) {
+    __shared__ float red[256][9];
+    const int nchunk = (N + 7) / 8;            // chunks per row
+    const int cpb = min(nchunk, 256);          // chunks handled per block column group
+    const int slots = 256 / cpb;               // row slots
+    const int chunk = blockIdx.y * cpb + (threadIdx.x % cpb);
+    const int slot = threadIdx.x / cpb;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r0 = blockIdx.x * CS_ROWS_PER_BLOCK;
+    const int r1 = min(M, r0 + CS_ROWS_PER_BLOCK);
+    if (chunk < nchunk && slot < slots) {
+        const int c0 = chunk * 8;
+        for (int r = r0 + slot; r < r1; r += slots) {
+            const T* p = X + (long)r * ld + c0;
+            if (c0 + 8 <= N) {
+                float v[8];
+                Vec8<T>::load(p, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += v[i];
+            } else {
+                for (int i = 0; i < 8 && c0 + i < N; ++i) acc[i] += to_f32<T>(p[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    if (slot == 0 && chunk < nchunk) {
+        const int c0 = chunk * 8;
+        for (int i = 0; i < 8 && c0 + i < N; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < slots; ++k) s += red[k * cpb + (threadIdx.x % cpb)][i];
+            atomicAdd(out + c0 + i, s);
+        }
+    }
+}
+
+extern "C" int athena_colsum(const void* X, int dtype, int M, int N, int ld, float* out, athena_stream_t stream) {
+    ATHENA_REQUIRE(X && out && M > 0 && N > 0 && ld >= N, ATHENA_E_SHAPE, "athena_colsum: bad arguments");
+    ATHENA_REQUIRE(ld % 8 == 0 && athena_aligned16(X), ATHENA_E_ALIGN, "athena_colsum: ld %% 8 and 16-byte alignment required");
+    hipStream_t s = (hipStream_t)stream;
+    ATHENA_REQUIRE(hipMemsetAsync(out, 0, sizeof(float) * N, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_colsum: memset failed");
+    const int nchunk = (N + 7) / 8;
+    const int cpb = nchunk < 256 ? nchunk : 256;
+    // 256 % cpb may be non-zero: the surplus threads idle (slot >= slots)
+    dim3 grid((M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK, (nchunk + cpb - 1) / cpb);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, M, N, ld, out);
+    else if (dtype == ATHENA_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, M, N, ld, out);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_colsum: dtype");
+    ATHENA_CHECK_LAUNCH("athena_colsum");
+    return ATHENA_OK;
+}
+
+// ================================================================ BatchNorm (+relu6)
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long rows, int C, float eps, float momentum,
+                                   float* __restrict__ mean_rstd, float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = (double)rows;
+    const double mu = stats[c] / n;
+    double var = stats[C + c] / n - mu * mu;
+    if (var < 0) var = 0;
+    mean_rstd[c] = (float)mu;
+    mean_rstd[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (moving_mean) moving_mean[c] = moving_mean[c] * momentum + (float)mu * (1.f - momentum);
+    if (moving_var) {
+        const double unb = rows > 1 ? var * n / (n - 1.0) : var;
+        moving_var[c] = moving_var[c] * momentum + (float)unb * (1.f - momentum);
+    }
+}
+
+extern "C" int athena_bn_finalize(const double* colstats, long rows, int C, float eps, float momentum,
+                                  float* mean_rstd, float* moving_mean, float* moving_var, athena_stream_t stream) {
+    ATHENA_REQUIRE(colstats && mean_rstd && rows > 0 && C > 0, ATHENA_E_SHAPE, "athena_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, colstats, rows, C,
+                       eps, momentum, mean_rstd, moving_mean, moving_var);
+    ATHENA_CHECK_LAUNCH("athena_bn_finalize");
+    return ATHENA_OK;
+}
+
+// y = relu6(x * sc[c] + sh[c]) with sc = gamma*rstd, sh = beta - mean*gamma*rstd (training) or the
+// moving-statistics equivalents (inference)
+template <typename T, bool INFER>
+__global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict__ x, const float* __restrict__ s0,
+                                                             const float* __restrict__ s1,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, long nchunks,
+                                                             int C, T* __restrict__ y) {
+    const int cpr = C / 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nchunks; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % cpr) * 8;
+        float v[8];
+        Vec8<T>::load(x + e * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i;
+            float mu, rs;
+            if (INFER) { mu = s0[c]; rs = rsqrtf(s1[c] + eps); }
+            else { mu = s0[c]; rs = s0[C + c]; }
+            v[i] = relu6f((v[i] - mu) * rs * gamma[c] + beta[c]);
+        }
+        Vec8<T>::store(y + e * 8, v);
+    }
+}
+
+static int bn_apply_common(const void* x, const float* s0, const float* s1, const float* gamma, const float* beta,
+                           float eps, long rows, int C, int dtype, void* y, bool infer, hipStream_t stream) {
+    ATHENA_REQUIRE(x && s0 && gamma && beta && y && rows > 0 && C > 0, ATHENA_E_SHAPE, "athena_bn_relu6: bad arguments");
+    ATHENA_REQUIRE(C % 8 == 0 && athena_aligned16(x) && athena_aligned16(y), ATHENA_E_ALIGN, "athena_bn_relu6: C %% 8 and 16-byte alignment required");
+    const long nchunks = rows * (C / 8);
+    long blocks = (nchunks + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks);
+#define BN_APPLY(T, I) hipLaunchKernelGGL((bn_relu6_apply_kernel<T, I>), grid, dim3(256), 0, stream, (const T*)x, s0, s1, gamma, beta, eps, nchunks, C, (T*)y)
+    if (dtype == ATHENA_BF16) { if (infer) BN_APPLY(bf16_t, true); else BN_APPLY(bf16_t, false); }
+    else if (dtype == ATHENA_F32) { if (infer) BN_APPLY(float, true); else BN_APPLY(float, false); }
+    else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6: dtype");
+#undef BN_APPLY
+    ATHENA_CHECK_LAUNCH("athena_bn_relu6_apply");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_bn_relu6_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta,
+                                     long rows, int C, int dtype, void* y, athena_stream_t stream) {
+    return bn_apply_common(x, mean_rstd, nullptr, gamma, beta, 0.f, rows, C, dtype, y, false, (hipStream_t)stream);
+}
+extern "C" int athena_bn_relu6_infer(const void* x, const float* moving_mean, const float* moving_var,
+                                     const float* gamma, const float* beta, float eps, long rows, int C, int dtype,
+                                     void* y, athena_stream_t stream) {
+    ATHENA_REQUIRE(moving_var, ATHENA_E_SHAPE, "athena_bn_relu6_infer: null moving_var");
+    return bn_apply_common(x, moving_mean, moving_var, gamma, beta, eps, rows, C, dtype, y, true, (hipStream_t)stream);
+}
+
+// reduce: scratch[c] += sum dy', scratch[C+c] += sum dy'*xhat over the block's rows
+#define BN_ROWS_PER_BLOCK 512
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ y,
+                                                            const float* __restrict__ mean_rstd, long rows, int C,
+                                                            double* __restrict__ scratch) {
+    __shared__ float red[256][17];
+    const int cpr = C / 8;
+    const int cpb = min(cpr, 256);
+    const int slots = 256 / cpb;
+    const int chunk = blockIdx.y * cpb + (threadIdx.x % cpb);
+    const int slot = threadIdx.x / cpb;
+    float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long r0 = (long)blockIdx.x * BN_ROWS_PER_BLOCK;
+    const long r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
+    if (chunk < cpr && slot < slots) {
+        const int c0 = chunk * 8;
+        float mu[8], rs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mu[i] = mean_rstd[c0 + i]; rs[i] = mean_rstd[C + c0 + i]; }
+        for (long r = r0 + slot; r < r1; r += slots) {
+            const long o = r * C + c0;
+            float dv[8], xv[8], yv[8];
+            Vec8<T>::load(dy + o, dv);
+            Vec8<T>::load(x + o, xv);
+            Vec8<T>::load(y + o, yv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float g = (yv[i] > 0.f && yv[i] < 6.f) ? dv[i] : 0.f;
+                a1[i] += g;
+                a2[i] += g * (xv[i] - mu[i]) * rs[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[threadIdx.x][i] = a1[i]; red[threadIdx.x][8 + i] = a2[i]; }
+    __syncthreads();
+    if (slot == 0 && chunk < cpr) {
+        const int c0 = chunk * 8;
+        for (int i = 0; i < 8; ++i) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < slots; ++k) {
+                s1 += red[k * cpb + (threadIdx.x % cpb)][i];
+                s2 += red[k * cpb + (threadIdx.x % cpb)][8 + i];
+            }
+            atomicAdd(scratch + c0 + i, (double)s1);
+            atomicAdd(scratch + C + c0 + i, (double)s2);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y,
+                                                           const float* __restrict__ mean_rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ scratch, long rows, int C,
+                                                           T* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    const int cpr = C / 8;
+    const long nchunks = rows * cpr;
+    const float inv_n = 1.f / (float)rows;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nchunks; e += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(e % cpr) * 8;
+        float dv[8], xv[8], yv[8], o[8];
+        Vec8<T>::load(dy + e * 8, dv);
+        Vec8<T>::load(x + e * 8, xv);
+        Vec8<T>::load(y + e * 8, yv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i;
+            const float mu = mean_rstd[c], rs = mean_rstd[C + c];
+            const float sb = (float)scratch[c], sg = (float)scratch[C + c];
+            const float g = (yv[i] > 0.f && yv[i] < 6.f) ? dv[i] : 0.f;
+            const float xh = (xv[i] - mu) * rs;
+            o[i] = gamma[c] * rs * (g - sb * inv_n - xh * sg * inv_n);
+        }
+        Vec8<T>::store(dx + e * 8, o);
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dbeta[c] = (float)scratch[c];
+            dgamma[c] = (float)scratch[C + c];
+        }
+    }
+}
+
+extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const void* y, const float* mean_rstd,
+                                   const float* gamma, long rows, int C, int dtype, double* scratch, void* dx,
+                                   float* dgamma, float* dbeta, athena_stream_t stream) {
+    ATHENA_REQUIRE(dy && x && y && mean_rstd && gamma && scratch && dx && dgamma && dbeta && rows > 0 && C > 0,
+                   ATHENA_E_SHAPE, "athena_bn_relu6_bwd: bad arguments");
+    ATHENA_REQUIRE(C % 8 == 0, ATHENA_E_ALIGN, "athena_bn_relu6_bwd: C %% 8 required");
+    const int cpr = C / 8;
+    ATHENA_REQUIRE(cpr >= 256 ? (cpr % 256 == 0) : (256 % cpr == 0 || true), ATHENA_E_SHAPE, "athena_bn_relu6_bwd: C");
+    hipStream_t s = (hipStream_t)stream;
+    ATHENA_REQUIRE(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * C, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_bn_relu6_bwd: memset failed");
+    const int cpb = cpr < 256 ? cpr : 256;
+    dim3 g1((unsigned)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK), (cpr + cpb - 1) / cpb);
+    const long nchunks = rows * cpr;
+    long blocks = (nchunks + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == ATHENA_BF16) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, mean_rstd, rows, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, mean_rstd, gamma, scratch, rows, C, (bf16_t*)dx, dgamma, dbeta);
+    } else if (dtype == ATHENA_F32) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)y, mean_rstd, rows, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)y, mean_rstd, gamma, scratch, rows, C, (float*)dx, dgamma, dbeta);
+    } else {
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6_bwd: dtype");
+    }
+    ATHENA_CHECK_LAUNCH("athena_bn_relu6_bwd");
+    return ATHENA_OK;
+}

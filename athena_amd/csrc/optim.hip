@@ -1,0 +1,150 @@
+// Per-tensor clip_by_norm + Adam with the warm-up schedule on flat fp32 buffers, and the
+// refresh of the bf16 weight shadows.  Pure streaming kernels (28 B/param for the update).
+#include "common.h"
+
+#define ADAM_CHUNK 4096   // elements per workgroup
+
+// binary search: largest i with seg_offsets[i] <= idx
+__device__ __forceinline__ int find_segment(const int64_t* __restrict__ off, int nseg, long idx) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= idx) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// sum of squares per tensor: each workgroup reduces one chunk; a chunk may straddle tensors
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long n,
+                                                         const int64_t* __restrict__ seg_offsets, int nseg,
+                                                         float gscale, float* __restrict__ norms) {
+    __shared__ float red[32];
+    const long c0 = (long)blockIdx.x * ADAM_CHUNK;
+    const long c1 = min(n, c0 + ADAM_CHUNK);
+    int seg = find_segment(seg_offsets, nseg, c0);
+    long pos = c0;
+    while (pos < c1) {
+        const long send = min(c1, (long)seg_offsets[seg + 1]);
+        float s = 0.f;
+        for (long i = pos + threadIdx.x; i < send; i += blockDim.x) {
+            float v = g[i] * gscale;
+            s += v * v;
+        }
+        s = block_sum(s, red);
+        if (threadIdx.x == 0 && send > pos) atomicAdd(norms + seg, s);
+        pos = send;
+        ++seg;
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n,
+                                                        const int64_t* __restrict__ seg_offsets, int nseg,
+                                                        const float* __restrict__ norms,
+                                                        const int64_t* __restrict__ step_ptr, athena_adam_cfg cfg,
+                                                        float* __restrict__ lr_out) {
+    const long step = step_ptr[0];
+    // learning rate of the warm-up schedule evaluated at ``step`` (0 on the very first update)
+    const float fs = (float)step;
+    const float arg1 = step > 0 ? rsqrtf(fs) : INFINITY;
+    const float arg2 = fs * powf(cfg.warmup_steps, -1.5f);
+    const float kk = cfg.k * powf(cfg.decay_rate, floorf(fs / cfg.decay_steps));
+    const float lr = kk * rsqrtf(cfg.d_model) * fminf(arg1, arg2);
+    const float t = fs + 1.f;
+    const float lr_t = lr * sqrtf(1.f - powf(cfg.beta2, t)) / (1.f - powf(cfg.beta1, t));
+    if (lr_out && blockIdx.x == 0 && threadIdx.x == 0) lr_out[0] = lr;
+
+    const long c0 = (long)blockIdx.x * ADAM_CHUNK;
+    const long c1 = min(n, c0 + ADAM_CHUNK);
+    int seg = find_segment(seg_offsets, nseg, c0);
+    long pos = c0;
+    while (pos < c1) {
+        const long send = min(c1, (long)seg_offsets[seg + 1]);
+        float scale = cfg.grad_scale;
+        if (cfg.clip_norm > 0.f) {
+            const float nrm = sqrtf(norms[seg]);
+            scale *= cfg.clip_norm / fmaxf(nrm, cfg.clip_norm);
+        }
+        for (long i = pos + threadIdx.x; i < send; i += blockDim.x) {
+            const float gi = g[i] * scale;
+            const float mi = cfg.beta1 * m[i] + (1.f - cfg.beta1) * gi;
+            const float vi = cfg.beta2 * v[i] + (1.f - cfg.beta2) * gi * gi;
+            m[i] = mi;
+            v[i] = vi;
+            p[i] -= lr_t * mi / (sqrtf(vi) + cfg.eps);
+        }
+        pos = send;
+        ++seg;
+    }
+}
+
+__global__ void step_increment_kernel(int64_t* step) { step[0] += 1; }
+
+extern "C" int athena_clip_adam_step(float* params, const float* grads, float* m, float* v, long n,
+                                     const int64_t* seg_offsets, int nseg, float* norms, int64_t* step,
+                                     const athena_adam_cfg* cfg, float* lr_out, athena_stream_t stream) {
+    ATHENA_REQUIRE(params && grads && m && v && seg_offsets && norms && step && cfg, ATHENA_E_SHAPE, "athena_clip_adam_step: null operand");
+    ATHENA_REQUIRE(n > 0 && nseg > 0, ATHENA_E_SHAPE, "athena_clip_adam_step: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    if (cfg->clip_norm > 0.f) {
+        ATHENA_REQUIRE(hipMemsetAsync(norms, 0, sizeof(float) * nseg, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_clip_adam_step: memset failed");
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, s, grads, n, seg_offsets, nseg, cfg->grad_scale, norms);
+    }
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, seg_offsets, nseg, norms, step, *cfg, lr_out);
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
+    ATHENA_CHECK_LAUNCH("athena_clip_adam_step");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- bf16 shadows
+// one workgroup per 32x32 tile of one matrix; writes the straight copy and the transposed copy
+__global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __restrict__ params,
+                                                              bf16_t* __restrict__ shadow,
+                                                              const int64_t* __restrict__ table, int nmat,
+                                                              const int64_t* __restrict__ tile_prefix) {
+    __shared__ float tile[32][33];
+    const long tid = blockIdx.x;
+    int mi = find_segment(tile_prefix, nmat, tid);
+    const int64_t* d = table + 7L * mi;
+    const long src = d[0];
+    const int rows = (int)d[1], cols = (int)d[2];
+    const long dst = d[3], ld_s = d[4], dst_t = d[5], ld_t = d[6];
+    const int tcols = (cols + 31) / 32;
+    const int local = (int)(tid - tile_prefix[mi]);
+    const int tr = local / tcols, tc = local - tr * tcols;
+    const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;    // 32 x 8
+    for (int y = y0; y < 32; y += 8) {
+        const int r = tr * 32 + y, c = tc * 32 + x;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = params[src + (long)r * cols + c];
+            shadow[dst + (long)r * ld_s + c] = (bf16_t)v;
+        }
+        tile[y][x] = v;
+    }
+    __syncthreads();
+    bf16_t* tdst = shadow + dst_t;
+    for (int y = y0; y < 32; y += 8) {
+        const int c = tc * 32 + y, r = tr * 32 + x;        // transposed: row index c, column index r
+        if (r < rows && c < cols) tdst[(long)c * ld_t + r] = (bf16_t)tile[x][y];
+    }
+}
+
+extern "C" int athena_refresh_shadows(const float* params, void* shadow, const int64_t* table, int nmat,
+                                      const int64_t* tile_prefix, long total_tiles, athena_stream_t stream) {
+    ATHENA_REQUIRE(params && shadow && table && tile_prefix && nmat > 0 && total_tiles > 0, ATHENA_E_SHAPE, "athena_refresh_shadows: bad arguments");
+    ATHENA_REQUIRE(total_tiles < (1L << 31), ATHENA_E_SHAPE, "athena_refresh_shadows: too many tiles");
+    hipLaunchKernelGGL(refresh_shadows_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params, (bf16_t*)shadow, table, nmat, tile_prefix);
+    ATHENA_CHECK_LAUNCH("athena_refresh_shadows");
+    return ATHENA_OK;
+}
+
+__global__ void advance_rng_kernel(uint64_t* st) { st[1] += 1; }
+extern "C" int athena_advance_rng(uint64_t* rng_state, athena_stream_t stream) {
+    ATHENA_REQUIRE(rng_state, ATHENA_E_SHAPE, "athena_advance_rng: null");
+    hipLaunchKernelGGL(advance_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    ATHENA_CHECK_LAUNCH("athena_advance_rng");
+    return ATHENA_OK;
+}

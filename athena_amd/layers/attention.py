@@ -1,0 +1,55 @@
+"""Multi-head attention (mirror of the reference's athena/layers/attention.py:25-171)."""
+import torch
+from torch import nn
+
+from ..runtime import truncated_normal
+from .commons import Dense
+
+
+class AttnMask:
+    """Mask of an attention call: ``key_mask`` uint8 [B, Tk] (1 = masked key) and ``causal``
+    (key j > query i masked).  Equivalent to the reference's float masks [B,1,1,Tk] and
+    [B,1,Tq,Tk] = max(key padding, look-ahead) (athena/utils/misc.py:68-90); the kernels add the
+    reference's ``mask * -1e9`` to the scaled scores."""
+
+    def __init__(self, key_mask, causal=False):
+        self.key_mask, self.causal = key_mask, causal
+
+    @staticmethod
+    def coerce(mask):
+        if mask is None:
+            return AttnMask(None, False)
+        if isinstance(mask, AttnMask):
+            return mask
+        if isinstance(mask, torch.Tensor) and mask.dim() == 4 and mask.shape[1] == 1 and mask.shape[2] == 1:
+            return AttnMask((mask[:, 0, 0, :] > 0).to(torch.uint8).contiguous(), False)
+        raise NotImplementedError("attention masks must be AttnMask objects or float tensors [B,1,1,Tk]")
+
+
+class MultiHeadAttention(nn.Module):
+    """wq / wk / wv / dense, all Dense(d_model) with truncated-normal(0.02) kernels
+    (attention.py:98-137).  ``forward(v, k, q, mask)`` keeps the reference's argument order."""
+
+    def __init__(self, store, name, d_model, num_heads, unidirectional=False, look_ahead=0):
+        super().__init__()
+        assert d_model % num_heads == 0
+        if unidirectional:
+            raise NotImplementedError("unidirectional attention (band mask, attention.py:55-58) is not built")
+        self.store, self.d_model, self.num_heads = store, d_model, num_heads
+        self.depth = d_model // num_heads
+        init = truncated_normal(0.02)
+        self.wq = Dense(store, name + ".wq", d_model, d_model, init)
+        self.wk = Dense(store, name + ".wk", d_model, d_model, init)
+        self.wv = Dense(store, name + ".wv", d_model, d_model, init)
+        self.dense = Dense(store, name + ".dense", d_model, d_model, init)
+
+    def forward(self, v, k, q, mask):
+        """Returns (output, None): the [B,h,Tq,Tk] attention weights are never materialised."""
+        from .fused import MultiHeadAttentionFn
+        if k is not v:
+            raise NotImplementedError("MultiHeadAttention: k and v must be the same tensor")
+        m = AttnMask.coerce(mask)
+        self.store.refresh_shadows()
+        out = MultiHeadAttentionFn.apply(q.contiguous(), k.contiguous(), self, m.key_mask, m.causal,
+                                         *self.parameters())
+        return out, None

@@ -1,0 +1,389 @@
+"""Forward/backward sequences of the model's blocks as coarse ``torch.autograd.Function``s.
+
+Each Function enqueues the HIP kernels of one block (x_net, y_net, an encoder layer, a decoder
+layer, a Dense head) and keeps the intermediates it needs for the backward pass.  Parameter
+gradients are written by the kernels straight into the flat gradient buffer (``param.grad`` is a
+view of it) and ``None`` is returned to autograd for them, so a backward pass OVERWRITES
+``.grad`` instead of accumulating into it.
+
+Reference sequences: athena/layers/transformer.py:296-310 (encoder layer), :374-388 (decoder
+layer), athena/layers/attention.py:147-171 (multi-head attention),
+athena/models/speech_transformer.py:72-113 (x_net / y_net).
+"""
+import math
+
+import torch
+
+from .. import ops
+from ..ops import ACT_GELU, ACT_MUL_DGELU, ACT_NONE, ACT_RELU6
+
+LN_EPS = 1e-8        # transformer.py:286-288
+BN_EPS = 1e-3        # Keras BatchNormalization default
+BN_MOMENTUM = 0.99   # Keras BatchNormalization default
+
+
+# ----------------------------------------------------------------------------------------------
+# Dense helpers.  ``dense`` is an athena_amd.layers.commons.Dense (kernel [K,N] fp32, bias [N]).
+# ----------------------------------------------------------------------------------------------
+def lin_fwd(x, M, dense, act=ACT_NONE, want_pre=False, drop_p=0.0, rng=None, site=0, out_dtype=None, ldc=None):
+    """y[M,N] = act(x[M,K] @ kernel + bias) (+dropout); returns (y, pre-activation or None)."""
+    K, N = dense.in_features, dense.out_features
+    ldc = ldc or N
+    out = torch.empty((M, ldc), dtype=out_dtype or x.dtype, device=x.device)
+    pre = torch.empty_like(out) if want_pre else None
+    if x.dtype == torch.bfloat16:
+        ops.gemm(x, dense.shadow_t, out, M, N, K, trans_b=True, lda=K, ldb=dense.shadow_t.shape[1], ldc=ldc,
+                 bias=dense.bias, act=act, c_pre=pre, drop_p=drop_p, rng_state=rng, rng_site=site)
+    else:
+        ops.gemm(x, dense.kernel, out, M, N, K, trans_b=False, lda=K, ldb=N, ldc=ldc, bias=dense.bias, act=act,
+                 c_pre=pre, drop_p=drop_p, rng_state=rng, rng_site=site)
+    return out, pre
+
+
+def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=None, drop_p=0.0, rng=None,
+              site=0):
+    """dx[M,K] (+)= (dy[M,N] @ kernel^T) * act'(aux) * dropout."""
+    K, N = dense.in_features, dense.out_features
+    if out is None:
+        out = torch.empty((M, K), dtype=dy.dtype, device=dy.device)
+    ldaux = aux.shape[-1] if aux is not None else 0
+    if dy.dtype == torch.bfloat16:
+        kc = ops.roundup(N, 8)    # padding columns of dy and of the shadow are zero
+        if lddy < kc:
+            raise RuntimeError("lin_bwd_x: dy leading dimension %d < %d" % (lddy, kc))
+        ops.gemm(dy, dense.shadow, out, M, K, kc, trans_b=True, lda=lddy, ldb=dense.shadow.shape[1], ldc=K,
+                 act=act, aux=aux, ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site)
+    else:
+        ops.gemm(dy, dense.kernel, out, M, K, N, trans_b=True, lda=lddy, ldb=N, ldc=K, act=act, aux=aux,
+                 ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site)
+    return out
+
+
+def lin_bwd_w(x, dy, M, dense, ldx, lddy):
+    """kernel.grad = x^T @ dy ; bias.grad = column sums of dy."""
+    K, N = dense.in_features, dense.out_features
+    ops.gemm(x, dy, dense.kernel.grad, K, N, M, trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0)
+    ops.colsum(dy, M, N, lddy, dense.bias.grad)
+
+
+# ----------------------------------------------------------------------------------------------
+# Multi-head attention block (reference athena/layers/attention.py:147-171)
+# ----------------------------------------------------------------------------------------------
+def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal):
+    d, h = attn.d_model, attn.num_heads
+    dk = d // h
+    q, _ = lin_fwd(q_in, B * Tq, attn.wq)
+    k, _ = lin_fwd(kv_in, B * Tk, attn.wk)
+    v, _ = lin_fwd(kv_in, B * Tk, attn.wv)
+    ctx = torch.empty((B * Tq, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, h, Tq), dtype=torch.float32, device=q.device)
+    ops.mha_fwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, d, lse)
+    out, _ = lin_fwd(ctx, B * Tq, attn.dense)
+    return out, (q, k, v, ctx, lse)
+
+
+def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, dq_in, acc_q, dkv_in, acc_kv):
+    """Writes parameter grads; adds/stores the input grads into dq_in / dkv_in (may be one tensor)."""
+    d, h = attn.d_model, attn.num_heads
+    dk = d // h
+    q, k, v, ctx, lse = saved
+    Mq, Mk = B * Tq, B * Tk
+    lin_bwd_w(ctx, dout, Mq, attn.dense, d, d)
+    dctx = lin_bwd_x(dout, Mq, attn.dense, d)
+    dq = torch.empty_like(q)
+    dk_ = torch.empty_like(k)
+    dv = torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    ops.mha_bwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, dctx, d, lse,
+                delta, dq, dk_, dv, d, d, d)
+    lin_bwd_w(q_in, dq, Mq, attn.wq, d, d)
+    lin_bwd_w(kv_in, dk_, Mk, attn.wk, d, d)
+    lin_bwd_w(kv_in, dv, Mk, attn.wv, d, d)
+    lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
+    lin_bwd_x(dk_, Mk, attn.wk, d, out=dkv_in, accumulate=acc_kv)
+    lin_bwd_x(dv, Mk, attn.wv, d, out=dkv_in, accumulate=True)
+
+
+def ffn_fwd(x, M, layer, p, rng):
+    """Dense(dff, gelu) -> Dropout -> Dense(d); the trailing Dropout is applied by the caller's
+    add+LayerNorm kernel (transformer.py:262-282)."""
+    h, h_pre = lin_fwd(x, M, layer.ffn0, act=ACT_GELU, want_pre=True, drop_p=p, rng=rng, site=layer.site_ffn_h)
+    f, _ = lin_fwd(h, M, layer.ffn1)
+    return f, (h_pre, h)
+
+
+def ffn_bwd(df, x, M, layer, saved, p, rng, dx):
+    """Parameter grads of the two Dense layers; dx += d(ffn)/dx."""
+    h_pre, h = saved
+    d, dff = layer.ffn0.in_features, layer.ffn0.out_features
+    lin_bwd_w(h, df, M, layer.ffn1, dff, d)
+    dh = lin_bwd_x(df, M, layer.ffn1, d, act=ACT_MUL_DGELU, aux=h_pre, drop_p=p, rng=rng, site=layer.site_ffn_h)
+    lin_bwd_w(x, dh, M, layer.ffn0, d, dff)
+    lin_bwd_x(dh, M, layer.ffn0, dff, out=dx, accumulate=True)
+
+
+def _params_of(*mods):
+    ps = []
+    for m in mods:
+        ps.extend(m.parameters())
+    return ps
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """TransformerEncoderLayer.call (reference athena/layers/transformer.py:296-310)."""
+
+    @staticmethod
+    def forward(ctx, x, layer, key_mask, training, *params):
+        B, T, d = x.shape
+        M = B * T
+        rng = layer.store.rng_state
+        p = layer.rate if training else 0.0
+        x2 = x.reshape(M, d)
+        a, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, False)
+        z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(x2, a, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
+                                                     layer.site_res1)
+        f, s_ffn = ffn_fwd(y1, M, layer, p, rng)
+        z2, y2, mean2, rstd2 = ops.add_layernorm_fwd(y1, f, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng,
+                                                     layer.site_res2)
+        ctx.layer, ctx.key_mask, ctx.p, ctx.shape = layer, key_mask, p, (B, T, d)
+        ctx.saved = (x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2)
+        return y2.view(B, T, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer, key_mask, p = ctx.layer, ctx.key_mask, ctx.p
+        B, T, d = ctx.shape
+        M = B * T
+        rng = layer.store.rng_state
+        x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2 = ctx.saved
+        ctx.saved = None
+        dy = dy.contiguous().view(M, d)
+        d_y1, df = ops.add_layernorm_bwd(dy, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
+                                         layer.norm2.gamma.grad, layer.norm2.beta.grad)
+        ffn_bwd(df, y1, M, layer, s_ffn, p, rng, d_y1)
+        dx, da = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
+                                       layer.norm1.gamma.grad, layer.norm1.beta.grad)
+        mha_block_bwd(da, x2, x2, layer.self_attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
+        return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class DecoderLayerFn(torch.autograd.Function):
+    """TransformerDecoderLayer.call (reference athena/layers/transformer.py:374-388)."""
+
+    @staticmethod
+    def forward(ctx, tgt, memory, layer, tgt_key_mask, mem_key_mask, training, *params):
+        B, L, d = tgt.shape
+        T = memory.shape[1]
+        M = B * L
+        rng = layer.store.rng_state
+        p = layer.rate if training else 0.0
+        t2 = tgt.reshape(M, d)
+        m2 = memory.reshape(B * T, d)
+        a1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True)
+        z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(t2, a1, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
+                                                     layer.site_res1)
+        a2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False)
+        z2, y2, mean2, rstd2 = ops.add_layernorm_fwd(y1, a2, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng,
+                                                     layer.site_res2)
+        f, s_ffn = ffn_fwd(y2, M, layer, p, rng)
+        z3, y3, mean3, rstd3 = ops.add_layernorm_fwd(y2, f, layer.norm3.gamma, layer.norm3.beta, LN_EPS, p, rng,
+                                                     layer.site_res3)
+        ctx.layer, ctx.masks, ctx.p, ctx.shape = layer, (tgt_key_mask, mem_key_mask), p, (B, L, T, d)
+        ctx.saved = (t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3)
+        return y3.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer, p = ctx.layer, ctx.p
+        tgt_key_mask, mem_key_mask = ctx.masks
+        B, L, T, d = ctx.shape
+        M = B * L
+        rng = layer.store.rng_state
+        t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3 = ctx.saved
+        ctx.saved = None
+        dy = dy.contiguous().view(M, d)
+        d_y2, df = ops.add_layernorm_bwd(dy, z3, mean3, rstd3, layer.norm3.gamma, p, rng, layer.site_res3,
+                                         layer.norm3.gamma.grad, layer.norm3.beta.grad)
+        ffn_bwd(df, y2, M, layer, s_ffn, p, rng, d_y2)
+        d_y1, da2 = ops.add_layernorm_bwd(d_y2, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
+                                          layer.norm2.gamma.grad, layer.norm2.beta.grad)
+        dmem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
+        mha_block_bwd(da2, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, False)
+        dtgt, da1 = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
+                                          layer.norm1.gamma.grad, layer.norm1.beta.grad)
+        mha_block_bwd(da1, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True)
+        return (dtgt.view(B, L, d), dmem.view(B, T, d), None, None, None, None) + \
+            (None,) * (len(ctx.needs_input_grad) - 6)
+
+
+class MultiHeadAttentionFn(torch.autograd.Function):
+    """Stand-alone MultiHeadAttention.call(v, k, q, mask) with k is v (attention.py:147-171)."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv_in, attn, key_mask, causal, *params):
+        B, Tq, d = q_in.shape
+        Tk = kv_in.shape[1]
+        q2, kv2 = q_in.reshape(B * Tq, d), kv_in.reshape(B * Tk, d)
+        out, saved = mha_block_fwd(q2, kv2, attn, B, Tq, Tk, key_mask, causal)
+        ctx.attn, ctx.key_mask, ctx.causal, ctx.shape = attn, key_mask, causal, (B, Tq, Tk, d)
+        ctx.same = q_in.data_ptr() == kv_in.data_ptr() and Tq == Tk
+        ctx.saved = (q2, kv2, saved)
+        return out.view(B, Tq, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Tq, Tk, d = ctx.shape
+        q2, kv2, saved = ctx.saved
+        ctx.saved = None
+        dout = dout.contiguous().view(B * Tq, d)
+        dq_in = torch.empty_like(q2)
+        dkv_in = torch.empty_like(kv2)
+        mha_block_bwd(dout, q2, kv2, ctx.attn, saved, B, Tq, Tk, ctx.key_mask, ctx.causal, dq_in, False, dkv_in,
+                      False)
+        return (dq_in.view(B, Tq, d), dkv_in.view(B, Tk, d), None, None, None) + \
+            (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+class DenseFn(torch.autograd.Function):
+    """y = x @ kernel + bias with an fp32 output whose rows are padded to a multiple of 8 columns
+    (the vocabulary projections: speech_transformer.py:130,151 and mtl_seq2seq.py:62,83).
+    Returns the padded tensor [B, T, Np]; the caller slices [..., :N]."""
+
+    @staticmethod
+    def forward(ctx, x, dense, kernel, bias):
+        B, T, K = x.shape
+        N = dense.out_features
+        Np = ops.roundup(N, 8)
+        x2 = x.reshape(B * T, K)
+        out, _ = lin_fwd(x2, B * T, dense, out_dtype=torch.float32, ldc=Np)
+        if Np != N:
+            out[:, N:].zero_()
+        ctx.dense, ctx.x2, ctx.shape = dense, x2, (B, T, K, N, Np)
+        return out.view(B, T, Np)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dense, x2 = ctx.dense, ctx.x2
+        B, T, K, N, Np = ctx.shape
+        M = B * T
+        dy = dy.contiguous().view(M, Np)
+        if x2.dtype != dy.dtype:
+            g = torch.empty((M, Np), dtype=x2.dtype, device=dy.device)
+            ops.cast(dy, g)
+            dy = g
+        lin_bwd_w(x2, dy, M, dense, K, Np)
+        dx = lin_bwd_x(dy, M, dense, Np)
+        ctx.x2 = None
+        return dx.view(B, T, K), None, None, None
+
+
+class XNetFn(torch.autograd.Function):
+    """x_net: Conv2D-BN-relu6 x2, reshape, Dense+relu6, +PE, dropout
+    (reference athena/models/speech_transformer.py:72-105)."""
+
+    @staticmethod
+    def forward(ctx, x0, net, training, *params):
+        st = net.store
+        cd = st.compute_dtype
+        dev = x0.device
+        B, T, Fd, nc = x0.shape
+        C, d = net.num_filters, net.d_model
+        T1, F1 = ops.same_out(T), ops.same_out(Fd)
+        T2, F2 = ops.same_out(T1), ops.same_out(F1)
+        rows1, rows2 = B * T1 * F1, B * T2 * F2
+        p = net.rate if training else 0.0
+        x0 = x0.contiguous()
+        stats = torch.empty(2 * C, dtype=torch.float64, device=dev) if training else None
+        # conv1 (few input channels: direct kernel on the fp32 input)
+        c1 = torch.empty((rows1, C), dtype=cd, device=dev)
+        ops.conv_small_cin_fwd(x0, net.conv1.kernel, c1, B, T, Fd, nc, C, stats)
+        a1 = torch.empty_like(c1)
+        mr1 = mr2 = None
+        if training:
+            mr1 = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            ops.bn_finalize(stats, rows1, C, BN_EPS, BN_MOMENTUM, mr1, net.bn1.moving_mean, net.bn1.moving_variance)
+            ops.bn_relu6_apply(c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, a1)
+        else:
+            ops.bn_relu6_infer(c1, net.bn1.moving_mean, net.bn1.moving_variance, net.bn1.gamma, net.bn1.beta,
+                               BN_EPS, rows1, C, a1)
+        # conv2 (implicit GEMM)
+        c2 = torch.empty((rows2, C), dtype=cd, device=dev)
+        if cd == torch.bfloat16:
+            ops.conv3x3s2_fwd(a1, net.conv2.shadow_t, 1, c2, B, T1, F1, C, C, stats)
+        else:
+            ops.conv3x3s2_fwd(a1, net.conv2.kernel, 0, c2, B, T1, F1, C, C, stats)
+        a2 = torch.empty_like(c2)
+        if training:
+            mr2 = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            ops.bn_finalize(stats, rows2, C, BN_EPS, BN_MOMENTUM, mr2, net.bn2.moving_mean, net.bn2.moving_variance)
+            ops.bn_relu6_apply(c2, mr2, net.bn2.gamma, net.bn2.beta, rows2, C, a2)
+        else:
+            ops.bn_relu6_infer(c2, net.bn2.moving_mean, net.bn2.moving_variance, net.bn2.gamma, net.bn2.beta,
+                               BN_EPS, rows2, C, a2)
+        # Reshape(-1, F2*C) is a view of the NHWC tensor; Dense + relu6; + PE; dropout
+        M = B * T2
+        y, _ = lin_fwd(a2.view(M, F2 * C), M, net.dense, act=ACT_RELU6)
+        out = torch.empty_like(y)
+        ops.add_pe_dropout(y, st.pe(d), B, T2, d, 1.0, p, st.rng_state, net.site_drop, out)
+        ctx.net, ctx.p, ctx.dims = net, p, (B, T, Fd, nc, C, d, T1, F1, T2, F2)
+        ctx.saved = (x0, c1, a1, mr1, c2, a2, mr2, y) if training else None
+        return out.view(B, T2, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("x_net: backward needs a training-mode forward")
+        net, p = ctx.net, ctx.p
+        st = net.store
+        B, T, Fd, nc, C, d, T1, F1, T2, F2 = ctx.dims
+        x0, c1, a1, mr1, c2, a2, mr2, y = ctx.saved
+        ctx.saved = None
+        dev = dout.device
+        rows1, rows2 = B * T1 * F1, B * T2 * F2
+        M = B * T2
+        dout = dout.contiguous().view(M, d)
+        dpre = torch.empty_like(dout)
+        ops.dropout_bwd(dout, 1.0, p, st.rng_state, net.site_drop, y, dpre)
+        a2m = a2.view(M, F2 * C)
+        lin_bwd_w(a2m, dpre, M, net.dense, F2 * C, d)
+        da2 = lin_bwd_x(dpre, M, net.dense, d)
+        scratch = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        dc2 = torch.empty_like(c2)
+        ops.bn_relu6_bwd(da2, c2, a2, mr2, net.bn2.gamma, rows2, C, scratch, dc2, net.bn2.gamma.grad,
+                         net.bn2.beta.grad)
+        ops.conv3x3s2_wgrad(a1, dc2, net.conv2.kernel.grad, B, T1, F1, C, C)
+        da1 = torch.empty_like(a1)
+        w_hwio = net.conv2.shadow if c2.dtype == torch.bfloat16 else net.conv2.kernel
+        ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
+        dc1 = torch.empty_like(c1)
+        ops.bn_relu6_bwd(da1, c1, a1, mr1, net.bn1.gamma, rows1, C, scratch, dc1, net.bn1.gamma.grad,
+                         net.bn1.beta.grad)
+        ops.conv_small_cin_wgrad(x0, dc1, net.conv1.kernel.grad, B, T, Fd, nc, C)
+        return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class YNetFn(torch.autograd.Function):
+    """y_net: Embedding, *sqrt(d) + PE, dropout (speech_transformer.py:108-113)."""
+
+    @staticmethod
+    def forward(ctx, ids, net, training, table):
+        st = net.store
+        B, L = ids.shape
+        d, V = net.d_model, net.num_class
+        p = net.rate if training else 0.0
+        ids = ids.contiguous()
+        out = torch.empty((B, L, d), dtype=st.compute_dtype, device=ids.device)
+        ops.embed_fwd(table, ids, st.pe(d), B, L, d, V, net.xscale, p, st.rng_state, net.site_drop, out)
+        ctx.net, ctx.ids, ctx.p = net, ids, p
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net, ids, p = ctx.net, ctx.ids, ctx.p
+        st = net.store
+        B, L = ids.shape
+        g = net.embedding.grad
+        g.zero_()
+        ops.embed_bwd(dout.contiguous(), ids, B, L, net.d_model, net.num_class, net.xscale, p, st.rng_state,
+                      net.site_drop, g)
+        return None, None, None, None

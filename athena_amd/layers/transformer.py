@@ -1,0 +1,128 @@
+"""Post-LN Transformer encoder/decoder (mirror of the reference's athena/layers/transformer.py:27-388)."""
+from torch import nn
+
+from ..runtime import truncated_normal
+from .attention import AttnMask, MultiHeadAttention
+from .commons import Dense, LayerNormParams
+
+
+class TransformerEncoderLayer(nn.Module):
+    """self-attention + FFN, each followed by dropout, residual add and LayerNorm(eps=1e-8)
+    (transformer.py:237-310)."""
+
+    def __init__(self, store, name, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="gelu",
+                 unidirectional=False, look_ahead=0, conv_module_kernel_size=0):
+        super().__init__()
+        if activation != "gelu":
+            raise NotImplementedError("only the default 'gelu' FFN activation is built")
+        if conv_module_kernel_size > 0:
+            raise NotImplementedError("conv_module_kernel_size > 0 (conformer conv module) is not built")
+        self.store, self.rate = store, dropout
+        self.self_attn = MultiHeadAttention(store, name + ".self_attn", d_model, nhead, unidirectional, look_ahead)
+        init = truncated_normal(0.02)
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init)
+        self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
+        self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
+        self.site_res1, self.site_ffn_h, self.site_res2 = store.new_site(), store.new_site(), store.new_site()
+
+    def forward(self, src, src_mask=None, training=None):
+        from .fused import EncoderLayerFn
+        m = AttnMask.coerce(src_mask)
+        return EncoderLayerFn.apply(src, self, m.key_mask, bool(training), *self.parameters())
+
+
+class TransformerDecoderLayer(nn.Module):
+    """masked self-attention, encoder-decoder attention, FFN (transformer.py:318-388)."""
+
+    def __init__(self, store, name, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="gelu"):
+        super().__init__()
+        if activation != "gelu":
+            raise NotImplementedError("only the default 'gelu' FFN activation is built")
+        self.store, self.rate = store, dropout
+        self.attn1 = MultiHeadAttention(store, name + ".attn1", d_model, nhead)
+        self.attn2 = MultiHeadAttention(store, name + ".attn2", d_model, nhead)
+        init = truncated_normal(0.02)
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init)
+        self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
+        self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
+        self.norm3 = LayerNormParams(store, name + ".norm3", d_model)
+        self.site_res1, self.site_res2 = store.new_site(), store.new_site()
+        self.site_ffn_h, self.site_res3 = store.new_site(), store.new_site()
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, training=None):
+        """Returns (output, None); the reference's second value (cross-attention weights) is not kept."""
+        from .fused import DecoderLayerFn
+        tm, mm = AttnMask.coerce(tgt_mask), AttnMask.coerce(memory_mask)
+        if not tm.causal and tgt_mask is not None:
+            raise NotImplementedError("decoder self-attention expects the causal target mask")
+        out = DecoderLayerFn.apply(tgt, memory, self, tm.key_mask, mm.key_mask, bool(training), *self.parameters())
+        return out, None
+
+
+class TransformerEncoder(nn.Module):
+    """stack of encoder layers (transformer.py:149-185)."""
+
+    def __init__(self, encoder_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(encoder_layers)
+
+    def forward(self, src, src_mask=None, training=None):
+        output = src
+        for layer in self.layers:
+            output = layer(output, src_mask=src_mask, training=training)
+        return output
+
+
+class TransformerDecoder(nn.Module):
+    """stack of decoder layers (transformer.py:188-234)."""
+
+    def __init__(self, decoder_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(decoder_layers)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, return_attention_weights=False, training=None):
+        output = tgt
+        for layer in self.layers:
+            output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, training=training)
+        if return_attention_weights:
+            raise NotImplementedError("attention weights are not materialised by the fused kernels")
+        return output
+
+
+class Transformer(nn.Module):
+    """encoder + decoder (transformer.py:27-146)."""
+
+    def __init__(self, store, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=2048, dropout=0.1, activation="gelu", unidirectional=False, look_ahead=0,
+                 custom_encoder=None, custom_decoder=None, conv_module_kernel_size=0):
+        super().__init__()
+        if custom_encoder is not None:
+            self.encoder = custom_encoder
+        else:
+            self.encoder = TransformerEncoder([
+                TransformerEncoderLayer(store, "encoder.%d" % i, d_model, nhead, dim_feedforward, dropout,
+                                        activation, unidirectional, look_ahead, conv_module_kernel_size)
+                for i in range(num_encoder_layers)])
+        if custom_decoder is not None:
+            self.decoder = custom_decoder
+        else:
+            self.decoder = TransformerDecoder([
+                TransformerDecoderLayer(store, "decoder.%d" % i, d_model, nhead, dim_feedforward, dropout,
+                                        activation)
+                for i in range(num_decoder_layers)])
+        self.d_model, self.nhead = d_model, nhead
+
+    def forward(self, src, tgt, src_mask=None, tgt_mask=None, memory_mask=None, return_encoder_output=False,
+                return_attention_weights=False, training=None):
+        if src.shape[0] != tgt.shape[0]:
+            raise RuntimeError("the batch number of src and tgt must be equal")
+        if src.shape[2] != self.d_model or tgt.shape[2] != self.d_model:
+            raise RuntimeError("the feature number of src and tgt must be equal to d_model")
+        memory = self.encoder(src, src_mask=src_mask, training=training)
+        output = self.decoder(tgt, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                              return_attention_weights=return_attention_weights, training=training)
+        if return_encoder_output:
+            return output, memory
+        return output

@@ -1,0 +1,133 @@
+"""CTC and label-smoothed cross-entropy losses (mirror of the reference's athena/loss.py:24-80)."""
+import torch
+
+from . import ops
+from .utils.misc import insert_eos_in_labels
+
+
+def _as_padded_rows(logits):
+    """Return (tensor whose storage the kernels read, ldl).  Logits produced by the model's
+    vocabulary projections are views [..., :V] of rows padded to a multiple of 8 columns and are
+    used in place; anything else is copied into such a buffer."""
+    V = logits.shape[-1]
+    try:
+        _, _, ld = ops._rows2d(logits)
+        ok = ld % 8 == 0 and logits.data_ptr() % 16 == 0 and logits.dtype in (torch.float32, torch.bfloat16)
+    except RuntimeError:
+        ok = False
+    if ok:
+        return logits, ld
+    ld = ops.roundup(V, 8)
+    buf = torch.zeros(logits.shape[:-1] + (ld,), dtype=torch.float32, device=logits.device)
+    buf[..., :V].copy_(logits)
+    return buf[..., :V], ld
+
+
+class _CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, label_len, logit_len, blank):
+        B, T, V = logits.shape
+        U = labels.shape[1]
+        src, ldl = _as_padded_rows(logits)
+        labels = labels.to(torch.int32).contiguous()
+        label_len = label_len.to(torch.int32).contiguous()
+        logit_len = logit_len.to(torch.int32).contiguous()
+        ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=logits.device)
+        per = torch.empty(B, dtype=torch.float32, device=logits.device)
+        ops.ctc_loss_fwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ops.group_sum(per, 1, B, 1.0 / B, out)          # tf.reduce_mean over the batch
+        ctx.saved = (src, ldl, labels, label_len, logit_len, ws)
+        ctx.dims = (B, T, V, U, blank)
+        ctx.per_sample = per
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, ldl, labels, label_len, logit_len, ws = ctx.saved
+        B, T, V, U, blank = ctx.dims
+        gs = gout.to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty((B, T, ldl), dtype=torch.float32, device=src.device)
+        ops.ctc_loss_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, gs, 1.0 / B, grad, ws)
+        return grad[..., :V], None, None, None, None
+
+
+class CTCLoss:
+    """CTC loss: tf.nn.ctc_loss on batch-major logits with dense labels, then the batch mean
+    (reference athena/loss.py:24-46)."""
+
+    def __init__(self, logits_time_major=False, blank_index=-1, name="CTCLoss"):
+        if logits_time_major:
+            raise NotImplementedError("time-major logits are not built (the reference never sets it)")
+        self.name = name
+        self.logits_time_major = logits_time_major
+        self.blank_index = blank_index
+        self.need_logit_length = True
+
+    def __call__(self, logits, samples, logit_length=None):
+        assert logit_length is not None
+        V = logits.shape[-1]
+        blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
+        return _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank)
+
+
+class _CELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, ls, mode):
+        B, L, V = logits.shape
+        src, ldl = _as_padded_rows(logits)
+        targets = targets.to(torch.int32).contiguous()
+        rows = B * L
+        row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        ops.ce_loss_fwd(src, ldl, targets, rows, V, ls, row_loss, lse)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        count = None
+        if mode == "by_token":
+            count = (targets != 0).sum().to(torch.float32).reshape(1)
+            ops.group_sum(row_loss, 1, rows, 1.0, out)
+            out = out / count
+            scale = 1.0
+        elif mode == "by_sequence":
+            scale = 1.0 / B
+            ops.group_sum(row_loss, 1, rows, scale, out)
+        else:
+            scale = 1.0 / rows
+            ops.group_sum(row_loss, 1, rows, scale, out)
+        ctx.saved = (src, ldl, targets, lse, count)
+        ctx.dims = (B, L, V, ls, scale)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, ldl, targets, lse, count = ctx.saved
+        B, L, V, ls, scale = ctx.dims
+        gs = gout.to(torch.float32).reshape(1)
+        if count is not None:
+            gs = gs / count
+        gs = gs.contiguous()
+        grad = torch.empty((B, L, ldl), dtype=torch.float32, device=src.device)
+        ops.ce_loss_bwd(src, ldl, targets, B * L, V, ls, lse, gs, scale, grad)
+        return grad[..., :V], None, None, None
+
+
+class Seq2SeqSparseCategoricalCrossentropy:
+    """Cross-entropy at each target position of each sequence, with eos appended, padding
+    (label 0) masked and optional label smoothing (reference athena/loss.py:49-80)."""
+
+    def __init__(self, num_classes, eos=-1, by_token=False, by_sequence=True, from_logits=True,
+                 label_smoothing=0.0):
+        if not from_logits:
+            raise NotImplementedError("only from_logits=True is built")
+        self.by_token = by_token
+        self.by_sequence = by_sequence
+        self.num_classes = num_classes
+        self.eos = num_classes + eos if eos < 0 else eos
+        self.smoothing_rate = label_smoothing
+
+    def __call__(self, logits, samples, logit_length=None):
+        labels = insert_eos_in_labels(samples["output"], self.eos, samples["output_length"])
+        seq_len = labels.shape[1]
+        logits = logits[:, :seq_len, :]
+        mode = "by_token" if self.by_token else ("by_sequence" if self.by_sequence else "mean")
+        return _CELossFn.apply(logits, labels, float(self.smoothing_rate), mode)

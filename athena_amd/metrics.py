@@ -1,0 +1,198 @@
+"""Accuracy metrics of the training step (mirror of the reference's athena/metrics.py:33-132).
+
+The arg-max over the vocabulary runs on the GPU (``athena_argmax_rows``); the greedy CTC
+collapse and the Levenshtein distance run on the host over a few thousand int32 ids, as they do
+in the reference (which pins them to /cpu:0).  Host work is deferred until ``result()`` so that
+a training step enqueues no device-to-host synchronisation.
+"""
+import logging
+
+import torch
+
+from . import ops
+from .utils.misc import validate_seqs
+
+
+def edit_distance(a, b):
+    """Levenshtein distance between two sequences (tf.edit_distance with normalize=False)."""
+    la, lb = len(a), len(b)
+    if la == 0:
+        return lb
+    if lb == 0:
+        return la
+    prev = list(range(lb + 1))
+    for i in range(1, la + 1):
+        cur = [i] + [0] * lb
+        ai = a[i - 1]
+        for j in range(1, lb + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ai != b[j - 1]))
+        prev = cur
+    return prev[lb]
+
+
+class _Sum:
+    """tf.keras.metrics.Sum"""
+
+    def __init__(self):
+        self.value = 0.0
+
+    def __call__(self, v):
+        self.value += float(v)
+
+    def result(self):
+        return self.value
+
+    def reset_states(self):
+        self.value = 0.0
+
+
+class Accuracy:
+    """Base class: accuracy = 1 - errors / total (metrics.py:33-63)."""
+
+    def __init__(self, name="Accuracy", rank_size=1):
+        self.name = name
+        self.error_count = _Sum()
+        self.total_count = _Sum()
+        self.rank_size = rank_size
+        self._pending = []
+
+    def reset_states(self):
+        self._drain()
+        self.error_count.reset_states()
+        self.total_count.reset_states()
+
+    def update_state(self, predictions, samples, logit_length=None):
+        raise NotImplementedError
+
+    def __call__(self, logits, samples, logit_length=None):
+        return self.update_state(logits, samples, logit_length)
+
+    def _drain(self):
+        pending, self._pending = self._pending, []
+        for fn in pending:
+            fn()
+
+    def flush(self):
+        """Move queued device results to pinned host memory (asynchronously) so the device
+        buffers may be reused; the host-side scoring still waits for ``result()``."""
+        new = []
+        for item in self._pending:
+            new.append(item.to_host() if hasattr(item, "to_host") else item)
+        self._pending = new
+
+    def result(self):
+        self._drain()
+        err, tot = self.error_count.result(), self.total_count.result()
+        if tot == 0.0:
+            return 0.0 if err > 0 else float("nan")   # x/0 = inf -> 0.0 ; 0/0 = nan
+        return 1.0 - err / tot
+
+
+class _Deferred:
+    """Device tensors of one update, scored on the host later."""
+
+    def __init__(self, owner, tensors, score):
+        self.owner, self.tensors, self.score, self.event = owner, tensors, score, None
+
+    def to_host(self):
+        if self.event is None and any(t.is_cuda for t in self.tensors):
+            host = []
+            for t in self.tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                host.append(h)
+            self.event = torch.cuda.Event()
+            self.event.record()
+            self.tensors = host
+        return self
+
+    def __call__(self):
+        self.to_host()
+        if self.event is not None:
+            self.event.synchronize()
+        self.score(*[t.cpu() for t in self.tensors])
+
+
+class CharactorAccuracy(Accuracy):
+    """Character accuracy from edit distances against the non-zero labels (metrics.py:66-89)."""
+
+    def __init__(self, name="CharactorAccuracy", rank_size=1):
+        super().__init__(name=name, rank_size=rank_size)
+
+    def update_state(self, predictions, samples, logit_length=None):
+        """``predictions``: list of python int lists (one hypothesis per utterance)."""
+        labels = samples["output"].cpu().tolist() if isinstance(samples["output"], torch.Tensor) else samples["output"]
+        return self._score(predictions, labels)
+
+    def _score(self, hyps, labels):
+        errs, count = 0.0, 0.0
+        for hyp, row in zip(hyps, labels):
+            ref = [c for c in row if c != 0]
+            errs += edit_distance(hyp, ref)
+            count += len(ref)
+        if self.rank_size > 1:
+            import torch.distributed as dist
+            t = torch.tensor([errs, count], dtype=torch.float64)
+            if dist.is_initialized():
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+                t = t.to(dev)
+                dist.all_reduce(t)
+                errs, count = float(t[0]), float(t[1])
+        self.error_count(errs)
+        self.total_count(count)
+        return errs, count
+
+
+class Seq2SeqSparseCategoricalAccuracy(CharactorAccuracy):
+    """Attention-decoder accuracy: argmax, cut at eos, drop zeros (metrics.py:92-106)."""
+
+    def __init__(self, eos, name="Seq2SeqSparseCategoricalAccuracy"):
+        super().__init__(name=name)
+        self.eos = eos
+
+    def __call__(self, logits, samples, logit_length=None):
+        B, L, V = logits.shape
+        _, _, ld = ops._rows2d(logits)
+        pred = torch.empty(B * L, dtype=torch.int32, device=logits.device)
+        ops.argmax_rows(logits.detach(), ld, B * L, V, pred)
+
+        def score(pred_h, labels_h):
+            hyps, _ = validate_seqs(pred_h.view(B, L), self.eos)
+            self._score(hyps, labels_h.tolist())
+
+        self._pending.append(_Deferred(self, [pred, samples["output"]], score))
+
+
+class CTCAccuracy(CharactorAccuracy):
+    """Greedy CTC decoding accuracy (metrics.py:109-132): argmax per frame up to logit_length,
+    merge repeats, drop the blank (last class)."""
+
+    def __init__(self, name="CTCAccuracy"):
+        super().__init__(name=name)
+        self.need_logit_length = True
+
+    def __call__(self, logits, samples, logit_length=None):
+        assert logit_length is not None
+        B, T, V = logits.shape
+        if T <= samples["output"].shape[1] + 1:
+            logging.warning("the length of logits is shorter than that of labels")
+            return
+        _, _, ld = ops._rows2d(logits)
+        pred = torch.empty(B * T, dtype=torch.int32, device=logits.device)
+        ops.argmax_rows(logits.detach(), ld, B * T, V, pred)
+
+        def score(pred_h, len_h, labels_h):
+            best = pred_h.view(B, T).tolist()
+            lens = len_h.tolist()
+            hyps = []
+            for b in range(B):
+                seq, prev = [], None
+                for t in range(int(lens[b])):
+                    c = best[b][t]
+                    if c != prev and c != V - 1:
+                        seq.append(c)
+                    prev = c
+                hyps.append(seq)
+            self._score(hyps, labels_h.tolist())
+
+        self._pending.append(_Deferred(self, [pred, logit_length, samples["output"]], score))

@@ -1,0 +1,4 @@
+"""Models of the hybrid attention/CTC training step (mirror of the reference's athena/models)."""
+from .base import BaseModel
+from .speech_transformer import SpeechTransformer
+from .mtl_seq2seq import MtlTransformerCtc

@@ -1,0 +1,167 @@
+"""Speech transformer (mirror of the reference's athena/models/speech_transformer.py:34-162)."""
+import logging
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers.commons import BatchNormParams, Conv3x3Params, Dense, bind_all
+from ..layers.fused import DenseFn, XNetFn, YNetFn
+from ..layers.transformer import Transformer
+from ..loss import Seq2SeqSparseCategoricalCrossentropy
+from ..metrics import Seq2SeqSparseCategoricalAccuracy
+from ..runtime import ParamStore, uniform
+from ..utils.hparam import register_and_parse_hparams
+from ..utils.misc import create_multihead_mask, insert_sos_in_labels
+from .base import BaseModel, to_device_samples
+
+_PRECISIONS = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+class XNet(nn.Module):
+    """Conv2D(3x3,s2,same,no bias)-BN-relu6 twice, reshape to (T', F'*C), Dense(d)+relu6,
+    positional encoding, dropout (speech_transformer.py:72-105)."""
+
+    def __init__(self, store, in_shape, num_filters, d_model, rate):
+        super().__init__()
+        self.store, self.num_filters, self.d_model, self.rate = store, num_filters, d_model, rate
+        feat, nc = int(in_shape[-2]), int(in_shape[-1])
+        if nc > 4:
+            raise NotImplementedError("x_net: more than 4 input channels is not built")
+        f2 = ops.same_out(ops.same_out(feat))
+        self.feat_dim, self.in_channels = feat, nc
+        self.conv1 = Conv3x3Params(store, "x_net.conv1", nc, num_filters, as_matrix=False)
+        self.bn1 = BatchNormParams(store, "x_net.bn1", num_filters)
+        self.conv2 = Conv3x3Params(store, "x_net.conv2", num_filters, num_filters, as_matrix=True)
+        self.bn2 = BatchNormParams(store, "x_net.bn2", num_filters)
+        self.dense = Dense(store, "x_net.dense", f2 * num_filters, d_model)
+        self.site_drop = store.new_site()
+
+    def forward(self, x0, training=None):
+        if x0.shape[-2] != self.feat_dim or x0.shape[-1] != self.in_channels:
+            raise ValueError("x_net: input feature shape %s, expected (%d, %d)" %
+                             (tuple(x0.shape[-2:]), self.feat_dim, self.in_channels))
+        return XNetFn.apply(x0, self, bool(training), *self.parameters())
+
+
+class YNet(nn.Module):
+    """Embedding(V, d) (uniform +-0.05), scaled positional encoding, dropout
+    (speech_transformer.py:108-113)."""
+
+    def __init__(self, store, num_class, d_model, rate):
+        super().__init__()
+        self.store, self.num_class, self.d_model, self.rate = store, num_class, d_model, rate
+        store.register("y_net.embedding", (num_class, d_model), uniform(-0.05, 0.05))
+        self.xscale = float(torch.sqrt(torch.tensor(float(d_model), dtype=torch.float32)))
+        self.site_drop = store.new_site()
+        self.embedding = None
+
+    def bind(self):
+        p = nn.Parameter(self.store.view("y_net.embedding"))
+        p.grad = self.store.grad_view("y_net.embedding")
+        self.embedding = p
+
+    def forward(self, y0, training=None):
+        return YNetFn.apply(y0, self, bool(training), self.embedding)
+
+
+class SpeechTransformer(BaseModel):
+    """x_net for the input, y_net for the shifted labels, the transformer and the output layer."""
+    default_config = {
+        "return_encoder_output": False,
+        "num_filters": 512,
+        "d_model": 512,
+        "num_heads": 8,
+        "num_encoder_layers": 12,
+        "num_decoder_layers": 6,
+        "dff": 1280,
+        "rate": 0.1,
+        "schedual_sampling_rate": 0.9,
+        "label_smoothing_rate": 0.0,
+        "unidirectional": False,
+        "look_ahead": 0,
+        "conv_module_kernel_size": 0
+    }
+
+    def __init__(self, data_descriptions, config=None, precision=None, store=None, seed=1, device=None):
+        super().__init__()
+        self.hparams = register_and_parse_hparams(self.default_config, config, cls=self.__class__)
+        self.num_class = data_descriptions.num_class + 1
+        self.sos = self.num_class - 1
+        self.eos = self.num_class - 1
+        ls_rate = self.hparams.label_smoothing_rate
+        self.loss_function = Seq2SeqSparseCategoricalCrossentropy(
+            num_classes=self.num_class, eos=self.eos, label_smoothing=ls_rate)
+        self.metric = Seq2SeqSparseCategoricalAccuracy(eos=self.eos, name="Accuracy")
+        self.data_descriptions = data_descriptions
+
+        own_store = store is None
+        if own_store:
+            import os
+            precision = precision or os.environ.get("ATHENA_PRECISION", "bf16")
+            store = ParamStore(_PRECISIONS[precision], device=device)
+        self.store = store
+        hp = self.hparams
+        self.x_net = XNet(store, data_descriptions.sample_shape["input"], hp.num_filters, hp.d_model, hp.rate)
+        self.y_net = YNet(store, self.num_class, hp.d_model, hp.rate)
+        self.transformer = Transformer(store, hp.d_model, hp.num_heads, hp.num_encoder_layers,
+                                       hp.num_decoder_layers, hp.dff, hp.rate, unidirectional=hp.unidirectional,
+                                       look_ahead=hp.look_ahead,
+                                       conv_module_kernel_size=hp.conv_module_kernel_size)
+        self.final_layer = Dense(store, "final_layer", hp.d_model, self.num_class)
+        if own_store:
+            self.finalize(seed)
+
+    def finalize(self, seed=1):
+        """Allocate the flat buffers and bind every Parameter view (once all variables are registered)."""
+        self.store.finalize(seed)
+        bind_all(self)
+        self.y_net.bind()
+
+    def prepare_samples(self, samples):
+        return to_device_samples(samples, self.store.device)
+
+    def call(self, samples, training=None):
+        self.store.refresh_shadows()
+        x0 = samples["input"]
+        y0 = insert_sos_in_labels(samples["output"], self.sos)
+        x = self.x_net(x0, training=training)
+        y = self.y_net(y0, training=training)
+        input_length = self.compute_logit_length(samples)
+        input_mask, output_mask = create_multihead_mask(x, input_length, y0)
+        y, encoder_output = self.transformer(x, y, input_mask, output_mask, input_mask, training=training,
+                                             return_encoder_output=True)
+        y = self._project(self.final_layer, y)
+        if self.hparams.return_encoder_output:
+            return y, encoder_output
+        return y
+
+    @staticmethod
+    def _project(dense, h):
+        """Dense(V): fp32 logits [B, T, V] as a view of rows padded to a multiple of 8 columns."""
+        out = DenseFn.apply(h, dense, dense.kernel, dense.bias)
+        return out[..., :dense.out_features]
+
+    def compute_logit_length(self, samples):
+        """ceil(ceil(len/2)/2) (speech_transformer.py:156-162)."""
+        n = samples["input_length"].to(torch.int32)
+        return (((n + 1) // 2) + 1) // 2
+
+    def restore_from_pretrained_model(self, pretrained_model, model_type=""):
+        if model_type == "":
+            return
+        if model_type in ("mpc", "SpeechTransformer"):
+            logging.info("loading from pretrained %s model", model_type)
+            state = pretrained_model.store.state_dict()
+            prefixes = ("x_net.", "encoder.") if model_type == "mpc" else \
+                ("x_net.", "y_net.", "encoder.", "decoder.", "final_layer.")
+            sub = {k: v for k, v in state.items() if k.startswith(prefixes) and k in self.store.by_name}
+            self.store.load_state_dict(sub, strict=False)
+        else:
+            raise ValueError("NOT SUPPORTED")
+
+    def time_propagate(self, history_logits, history_predictions, step, enc_outputs):
+        raise NotImplementedError("decoding (speech_transformer.py:164-238) is outside the built training path")
+
+    def decode(self, samples, hparams, decoder, return_encoder=False):
+        raise NotImplementedError("decoding (speech_transformer.py:196-238) is outside the built training path")

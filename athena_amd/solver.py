@@ -1,0 +1,205 @@
+"""Training / evaluation loops (mirror of the reference's athena/solver.py:45-218).
+
+``BaseSolver.train_step`` = forward, loss, backward, per-tensor clip + Adam (one fused kernel).
+``HorovodSolver`` is the data-parallel solver: one process per GPU under ``torchrun``, the flat
+gradient buffer is averaged across ranks with bucketed all-reduces on RCCL
+(``torch.distributed`` backend "nccl") in place of ``hvd.DistributedGradientTape``.
+"""
+import logging
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .utils.hparam import register_and_parse_hparams
+from .utils.metric_check import MetricChecker
+
+
+class BaseSolver:
+    """Base Solver."""
+    default_config = {
+        "clip_norm": 100.0,
+        "log_interval": 10,
+        "enable_tf_function": True
+    }
+
+    def __init__(self, model, optimizer, sample_signature=None, eval_sample_signature=None, config=None, **kwargs):
+        self.model = model
+        self.optimizer = optimizer
+        if getattr(optimizer, "store", None) is None:
+            optimizer.attach(model.store)
+        self.metric_checker = MetricChecker(self.optimizer)
+        self.sample_signature = sample_signature
+        self.eval_sample_signature = eval_sample_signature
+        self.hparams = register_and_parse_hparams(self.default_config, config, cls=self.__class__)
+        self.world_size = 1
+        self.rank = 0
+
+    @staticmethod
+    def initialize_devices(solver_gpus=None):
+        """Select the GPU of this process (solver.py:63-76)."""
+        if torch.cuda.is_available():
+            idx = solver_gpus[0] if solver_gpus else 0
+            torch.cuda.set_device(idx)
+
+    @staticmethod
+    def clip_by_norm(grads, norm):
+        """tf.clip_by_norm per tensor on a list of gradients (solver.py:78-87).  The training step
+        itself uses the fused clip inside the Adam kernel; this stays for API compatibility."""
+        if norm <= 0:
+            return grads
+        out = []
+        for g in grads:
+            if g is None:
+                out.append(None)
+                continue
+            n = torch.linalg.vector_norm(g.float())
+            out.append(g * (norm / torch.clamp(n, min=norm)).to(g.dtype))
+        return out
+
+    # ------------------------------------------------------------------ one step
+    def _forward_backward(self, samples):
+        outputs = self.model(samples, training=True)
+        loss, metrics = self.model.get_loss(outputs, samples, training=True)
+        total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
+        total_loss.backward()
+        return loss, metrics
+
+    def _reduce_gradients(self):
+        """Hook for data parallelism; returns the factor the optimizer applies to the gradients."""
+        return 1.0
+
+    def _flush_metrics(self):
+        for m in (getattr(self.model, "metric", None), getattr(getattr(self.model, "model", None), "metric", None)):
+            if m is not None and hasattr(m, "flush"):
+                m.flush()
+
+    def train_step(self, samples):
+        """train the model 1 step (solver.py:89-99)."""
+        loss, metrics = self._forward_backward(samples)
+        scale = self._reduce_gradients()
+        self.optimizer.apply_gradients(clip_norm=self.hparams.clip_norm, grad_scale=scale)
+        ops.advance_rng(self.model.store.rng_state)
+        self._flush_metrics()
+        return loss, metrics
+
+    def train(self, dataset, total_batches=-1):
+        """Update the model in 1 epoch (solver.py:101-113)."""
+        for batch, samples in enumerate(dataset):
+            if 0 <= total_batches <= batch:
+                break
+            samples = self.model.prepare_samples(samples)
+            loss, metrics = self.train_step(samples)
+            if batch % self.hparams.log_interval == 0 and self.rank == 0:
+                logging.info(self.metric_checker(loss, metrics))
+                self.model.reset_metrics()
+
+    def evaluate_step(self, samples):
+        """evaluate the model 1 step (solver.py:115-120)."""
+        with torch.no_grad():
+            outputs = self.model(samples, training=False)
+            loss, metrics = self.model.get_loss(outputs, samples, training=False)
+        self._flush_metrics()
+        return loss, metrics
+
+    def evaluate(self, dataset, epoch=0):
+        """evaluate the model (solver.py:122-140)."""
+        loss_sum, n = 0.0, 0
+        loss, metrics = None, None
+        self.model.reset_metrics()
+        for batch, samples in enumerate(dataset):
+            samples = self.model.prepare_samples(samples)
+            loss, metrics = self.evaluate_step(samples)
+            if batch % self.hparams.log_interval == 0 and self.rank == 0:
+                logging.info(self.metric_checker(loss, metrics, -2))
+            total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
+            loss_sum += float(total_loss)
+            n += 1
+        mean_loss = loss_sum / max(n, 1)
+        if metrics is not None:
+            metrics = {k: float(v) for k, v in metrics.items()}
+        if self.rank == 0:
+            logging.info(self.metric_checker(mean_loss, metrics, evaluate_epoch=epoch))
+        self.model.reset_metrics()
+        return mean_loss, metrics
+
+
+def bucket_ranges(seg_offsets, n_total, bucket_elems):
+    """Cut the flat gradient buffer [0, n_total) into contiguous ranges of about ``bucket_elems``
+    elements that end on variable boundaries, listed from the END of the buffer (the variables
+    registered last receive their gradients first in the backward pass)."""
+    bounds = sorted(set(int(o) for o in seg_offsets) | {0, int(n_total)})
+    ranges = []
+    end = int(n_total)
+    idx = len(bounds) - 1
+    while end > 0:
+        start = end
+        while idx > 0 and (end - start) < bucket_elems:
+            idx -= 1
+            start = bounds[idx]
+        ranges.append((start, end))
+        end = start
+    return ranges
+
+
+class HorovodSolver(BaseSolver):
+    """Data-parallel solver: per-rank batches, gradients averaged over ranks before the clip
+    (solver.py:142-218).  Launch with ``torchrun --nproc-per-node N``; the name is kept so that
+    ``from athena import HorovodSolver`` keeps working."""
+
+    BUCKET_MB = float(os.environ.get("ATHENA_DP_BUCKET_MB", "25"))
+
+    def __init__(self, model, optimizer, sample_signature=None, eval_sample_signature=None, config=None, **kwargs):
+        super().__init__(model, optimizer, sample_signature, eval_sample_signature, config, **kwargs)
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        st = model.store
+        self._buckets = bucket_ranges(st.seg_offsets.tolist(), st.n_train, int(self.BUCKET_MB * (1 << 20) / 4))
+        self._broadcast_done = False
+
+    @staticmethod
+    def initialize_devices(solver_gpus=None):
+        """Join the process group (RANK / WORLD_SIZE / MASTER_* from the environment) and pin this
+        process to its GPU (solver.py:146-160)."""
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if torch.cuda.is_available():
+            idx = solver_gpus[local_rank] if solver_gpus else local_rank
+            torch.cuda.set_device(idx)
+        if not dist.is_initialized() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            dist.init_process_group(backend=backend)
+
+    def broadcast_variables(self):
+        """hvd.broadcast_variables(root_rank=0) of the model and optimizer state (solver.py:192-194)."""
+        if self.world_size > 1:
+            st = self.model.store
+            dist.broadcast(st.params, src=0)
+            for t in self.optimizer.variables():
+                dist.broadcast(t, src=0)
+            st.shadows_dirty = True
+        self._broadcast_done = True
+
+    def _reduce_gradients(self):
+        """Sum the flat gradient buffer over ranks bucket by bucket; the 1/world_size of the
+        average is folded into the optimizer kernel."""
+        if self.world_size == 1:
+            return 1.0
+        g = self.model.store.grads
+        works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in self._buckets]
+        for w in works:
+            w.wait()
+        return 1.0 / self.world_size
+
+    def train(self, dataset, total_batches=-1):
+        """Update the model in 1 epoch (solver.py:176-197)."""
+        for batch, samples in enumerate(dataset):
+            if 0 <= total_batches <= batch:
+                break
+            samples = self.model.prepare_samples(samples)
+            loss, metrics = self.train_step(samples)
+            if batch == 0 and not self._broadcast_done:
+                self.broadcast_variables()
+            if batch % self.hparams.log_interval == 0 and self.rank == 0:
+                logging.info(self.metric_checker(loss, metrics))
+                self.model.reset_metrics()

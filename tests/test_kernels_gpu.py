@@ -1,0 +1,528 @@
+"""Parity of each HIP entry point (called through the C ABI) against the CPU oracle on seeded
+inputs.  fp32 kernels must agree to ~1e-5 relative; bf16 storage to ~1e-2 (8 bits of mantissa)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ctc as octc
+from oracle import model as om
+from tests.util import TOL, assert_close, dev, rel_err, rounded, to_cd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from athena_amd import ops as o
+    return o
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(200, 72, 64), (136, 264, 96), (1000, 520, 40), (64, 64, 512)])
+def test_gemm_layouts(ops, cd, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g, dtype=torch.float64)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=g, dtype=torch.float64)
+    Ar, Br = rounded(A, cd), rounded(Bm, cd)
+    ref = (Ar.t() if ta else Ar) @ (Br.t() if tb else Br)
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    ops.gemm(to_cd(A, cd), to_cd(Bm, cd), C, M, N, K, trans_a=ta, trans_b=tb)
+    assert_close(C, ref, 2e-5 if cd == torch.float32 else 1e-5, "gemm")   # products of rounded inputs are exact in fp32 acc
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+def test_gemm_epilogues(ops, cd):
+    M, N, K = 150, 88, 64
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    W = torch.randn(K, N, generator=g, dtype=torch.float64) * 0.3
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    Ar, Wr = rounded(A, cd), rounded(W, cd)
+    pre_ref = Ar @ Wr + bias
+    tol = TOL[cd]
+    # bias + gelu with pre-activation copy
+    C = torch.empty(M, N, dtype=cd, device=dev())
+    P = torch.empty(M, N, dtype=cd, device=dev())
+    ops.gemm(to_cd(A, cd), to_cd(W, cd), C, M, N, K, bias=bias.float().to(dev()), act=ops.ACT_GELU, c_pre=P)
+    assert_close(P, pre_ref, tol, "pre-activation")
+    assert_close(C, om.gelu_tanh(pre_ref), tol, "gelu")
+    # relu6
+    ops.gemm(to_cd(A, cd), to_cd(W, cd), C, M, N, K, bias=bias.float().to(dev()), act=ops.ACT_RELU6)
+    assert_close(C, om.relu6(pre_ref), tol, "relu6")
+    # backward epilogue: multiply by gelu'(aux)
+    H = torch.randn(M, N, generator=g, dtype=torch.float64)
+    Hr = rounded(H, cd).requires_grad_(True)
+    om.gelu_tanh(Hr).sum().backward()
+    ops.gemm(to_cd(A, cd), to_cd(W, cd), C, M, N, K, act=ops.ACT_MUL_DGELU, aux=to_cd(H, cd), ldaux=N)
+    assert_close(C, (Ar @ Wr) * Hr.grad, tol, "mul_dgelu")
+    # relu6 gate from the saved output
+    Y = om.relu6(torch.randn(M, N, generator=g, dtype=torch.float64) * 4)
+    Yr = rounded(Y, cd)
+    ops.gemm(to_cd(A, cd), to_cd(W, cd), C, M, N, K, act=ops.ACT_MUL_DRELU6, aux=to_cd(Y, cd), ldaux=N)
+    assert_close(C, (Ar @ Wr) * ((Yr > 0) & (Yr < 6)).double(), tol, "mul_drelu6")
+    # accumulate
+    C0 = torch.randn(M, N, generator=g, dtype=torch.float64)
+    C = to_cd(C0, torch.float32)
+    ops.gemm(to_cd(A, cd), to_cd(W, cd), C, M, N, K, accumulate=True)
+    assert_close(C, Ar @ Wr + C0.float().double(), 2e-5, "accumulate")
+    # automatic split-K (the weight-gradient shape: long contraction, small output)
+    X = torch.randn(3000, 72, generator=g, dtype=torch.float64)
+    dY = torch.randn(3000, 48, generator=g, dtype=torch.float64)
+    G = torch.full((72, 48), float("nan"), dtype=torch.float32, device=dev())
+    ops.gemm(to_cd(X, cd), to_cd(dY, cd), G, 72, 48, 3000, trans_a=True, trans_b=False, split_k=0)
+    assert_close(G, rounded(X, cd).t() @ rounded(dY, cd), 2e-5, "split-k")
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+def test_gemm_dropout_consistency(ops, cd):
+    """Same site + state gives the same mask in the forward and the backward epilogue."""
+    M, N, K = 96, 64, 32
+    g = torch.Generator().manual_seed(9)
+    A = to_cd(torch.randn(M, K, generator=g, dtype=torch.float64), cd)
+    W = to_cd(torch.randn(K, N, generator=g, dtype=torch.float64), cd)
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device=dev())
+    C0 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    C1 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    C2 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(A, W, C0, M, N, K)
+    ops.gemm(A, W, C1, M, N, K, drop_p=0.25, rng_state=rng, rng_site=3)
+    ops.gemm(A, W, C2, M, N, K, drop_p=0.25, rng_state=rng, rng_site=3)
+    assert torch.equal(C1, C2)
+    kept = C1 != 0
+    frac = float(kept.float().mean())
+    assert 0.70 < frac < 0.80, frac
+    assert_close(C1[kept], C0[kept] / 0.75, 1e-6, "dropout scale")
+    ops.gemm(A, W, C2, M, N, K, drop_p=0.25, rng_state=rng, rng_site=4)
+    assert not torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+def test_colsum(ops, cd):
+    g = torch.Generator().manual_seed(2)
+    for M, N, ld in [(300, 40, 40), (1000, 4233, 4240), (77, 8, 16)]:
+        X = torch.randn(M, ld, generator=g, dtype=torch.float64)
+        out = torch.empty(N, dtype=torch.float32, device=dev())
+        ops.colsum(to_cd(X, cd), M, N, ld, out)
+        assert_close(out, rounded(X, cd)[:, :N].sum(0), 1e-5, "colsum")
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("rows,d", [(37, 32), (260, 256), (50, 512), (9, 1000)])
+def test_add_layernorm(ops, cd, rows, d):
+    g = torch.Generator().manual_seed(rows + d)
+    a = torch.randn(rows, d, generator=g, dtype=torch.float64)
+    b = torch.randn(rows, d, generator=g, dtype=torch.float64)
+    gamma = torch.rand(d, generator=g, dtype=torch.float64) + 0.5
+    beta = torch.randn(d, generator=g, dtype=torch.float64)
+    dy = torch.randn(rows, d, generator=g, dtype=torch.float64)
+    ar, br = rounded(a, cd), rounded(b, cd)
+    zr = rounded(ar + br, cd).requires_grad_(True)       # the kernel stores z in the compute dtype
+    gm, bt = gamma.float().double().requires_grad_(True), beta.float().double().requires_grad_(True)
+    y_ref = om.layer_norm(zr, gm, bt, 1e-8)
+    (y_ref * rounded(dy, cd)).sum().backward()
+    gam_d, bet_d = gamma.float().to(dev()), beta.float().to(dev())
+    z, y, mean, rstd = ops.add_layernorm_fwd(to_cd(a, cd), to_cd(b, cd), gam_d, bet_d, 1e-8, 0.0, None, 0)
+    tol = TOL[cd]
+    assert_close(z, zr.detach(), 1e-6 if cd == torch.float32 else 1e-2, "z")
+    assert_close(y, y_ref.detach(), tol, "y")
+    dgamma = torch.empty(d, dtype=torch.float32, device=dev())
+    dbeta = torch.empty(d, dtype=torch.float32, device=dev())
+    da, db = ops.add_layernorm_bwd(to_cd(dy, cd), z, mean, rstd, gam_d, 0.0, None, 0, dgamma, dbeta)
+    assert da is db
+    assert_close(da, zr.grad, tol * 2, "dz")
+    assert_close(dgamma, gm.grad, tol * 2, "dgamma")
+    assert_close(dbeta, bt.grad, tol, "dbeta")
+
+
+def test_add_layernorm_dropout(ops):
+    rows, d = 64, 128
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(rows, d, generator=g).to(dev())
+    b = torch.randn(rows, d, generator=g).to(dev())
+    gam, bet = torch.ones(d, device=dev()), torch.zeros(d, device=dev())
+    rng = torch.tensor([99, 1], dtype=torch.int64, device=dev())
+    z, y, mean, rstd = ops.add_layernorm_fwd(a, b, gam, bet, 1e-8, 0.5, rng, 11)
+    m = (z - a) / b                      # 0 or 2
+    assert set(torch.unique(torch.round(m)).tolist()) <= {0.0, 2.0}
+    dg, dbt = torch.empty(d, device=dev()), torch.empty(d, device=dev())
+    dy = torch.randn(rows, d, generator=g).to(dev())
+    da, db = ops.add_layernorm_bwd(dy, z, mean, rstd, gam, 0.5, rng, 11, dg, dbt)
+    assert_close(db, da * torch.round(m), 1e-6, "db = dz * mask")
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v, key_mask, causal, scale):
+    B, Tq, h, dk = q.shape
+    Tk = k.shape[1]
+    qh, kh, vh = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    logits = qh @ kh.transpose(-1, -2) * scale
+    mask = torch.zeros(B, 1, Tq, Tk, dtype=q.dtype)
+    if key_mask is not None:
+        mask = torch.maximum(mask, key_mask.to(q.dtype)[:, None, None, :])
+    if causal:
+        mask = torch.maximum(mask, 1 - torch.tril(torch.ones(Tq, Tk, dtype=q.dtype)))
+    logits = logits + mask * -1e9
+    w = torch.softmax(logits, -1)
+    return (w @ vh).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("B,h,Tq,Tk,dk,causal", [(2, 4, 37, 37, 8, False), (3, 2, 19, 19, 32, True),
+                                                (2, 4, 33, 70, 64, False), (1, 8, 130, 130, 32, False),
+                                                (2, 2, 5, 5, 16, True)])
+def test_mha(ops, cd, B, h, Tq, Tk, dk, causal):
+    g = torch.Generator().manual_seed(B * 100 + Tq + dk)
+    d = h * dk
+    q = torch.randn(B, Tq, h, dk, generator=g, dtype=torch.float64)
+    k = torch.randn(B, Tk, h, dk, generator=g, dtype=torch.float64)
+    v = torch.randn(B, Tk, h, dk, generator=g, dtype=torch.float64)
+    do = torch.randn(B, Tq, h, dk, generator=g, dtype=torch.float64)
+    key_mask = torch.zeros(B, Tk, dtype=torch.uint8)
+    for b in range(B):
+        n = int(torch.randint(1, Tk + 1, (1,), generator=g))
+        key_mask[b, n:] = 1
+    if causal:
+        key_mask[:, 0] = 0
+        if Tk > 3:
+            key_mask[0, 2] = 1      # a masked key in the middle (label id 0 inside a sequence)
+    scale = 1.0 / math.sqrt(dk)
+    qr, kr, vr = (rounded(t, cd).requires_grad_(True) for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, key_mask, causal, scale)
+    (ref * rounded(do, cd)).sum().backward()
+    qd, kd, vd, dod = (to_cd(t, cd) for t in (q, k, v, do))
+    out = torch.empty(B, Tq, h, dk, dtype=cd, device=dev())
+    lse = torch.empty(B, h, Tq, dtype=torch.float32, device=dev())
+    km = key_mask.to(dev())
+    ops.mha_fwd(qd, kd, vd, d, d, d, km, causal, B, h, Tq, Tk, dk, scale, out, d, lse)
+    tol = 1e-4 if cd == torch.float32 else 2e-2
+    assert_close(out, ref.detach(), tol, "attention out")
+    dq, dk_, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    delta = torch.empty_like(lse)
+    # the backward is fed the oracle's (rounded) forward output so the two passes are tested apart
+    out_in = to_cd(ref.detach(), cd)
+    ops.mha_bwd(qd, kd, vd, d, d, d, km, causal, B, h, Tq, Tk, dk, scale, out_in, dod, d, lse, delta, dq, dk_, dv,
+                d, d, d)
+    assert_close(dq, qr.grad, tol * 2, "dq")
+    assert_close(dk_, kr.grad, tol * 2, "dk")
+    assert_close(dv, vr.grad, tol * 2, "dv")
+
+
+def test_mha_fully_masked_row_is_uniform(ops):
+    """mask * -1e9 in fp32 swallows the scores: a row whose keys are all masked averages V."""
+    B, h, T, dk = 1, 1, 6, 8
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(B, T, h, dk, generator=g).to(dev()) for _ in range(3))
+    km = torch.ones(B, T, dtype=torch.uint8, device=dev())
+    out = torch.empty_like(q)
+    lse = torch.empty(B, h, T, device=dev())
+    ops.mha_fwd(q, k, v, dk, dk, dk, km, False, B, h, T, T, dk, 1.0, out, dk, lse)
+    assert_close(out[0, 0, 0], v[0, :, 0].mean(0), 1e-5, "uniform")
+
+
+# ------------------------------------------------------------------------------------------ conv / BN
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 10, 16, 24), (1, 13, 7, 8, 16), (3, 20, 9, 32, 136),
+                                            (2, 31, 5, 24, 8)])
+def test_conv3x3s2(ops, cd, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 3, Cin, Cout, generator=g, dtype=torch.float64) * 0.2
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g, dtype=torch.float64)
+    xr, wr = rounded(x, cd).requires_grad_(True), rounded(w, cd).requires_grad_(True)
+    ref = om.conv2d_same_s2(xr, wr)
+    (ref * rounded(dy, cd)).sum().backward()
+    tol = 2e-5 if cd == torch.float32 else 1.5e-2
+    xd, dyd = to_cd(x, cd), to_cd(dy, cd)
+    w_hwio = to_cd(w, cd)
+    w_t = to_cd(w.permute(3, 0, 1, 2), cd)          # [Cout][3][3][Cin]
+    stats = torch.empty(2 * Cout, dtype=torch.float64, device=dev())
+    for layout, wd in ((0, w_hwio), (1, w_t)):
+        out = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=cd, device=dev())
+        ops.conv3x3s2_fwd(xd, wd, layout, out, B, H, W, Cin, Cout, stats)
+        assert_close(out, ref.detach(), tol, "conv fwd layout %d" % layout)
+        o64 = out.double().cpu().reshape(-1, Cout)
+        assert_close(stats[:Cout], o64.sum(0), 1e-5, "channel sums")
+        assert_close(stats[Cout:], (o64 * o64).sum(0), 1e-5, "channel sums of squares")
+    din = torch.full((B, H, W, Cin), float("nan"), dtype=cd, device=dev())
+    ops.conv3x3s2_dgrad(dyd, w_hwio, din, B, H, W, Cin, Cout)
+    assert_close(din, xr.grad, tol, "conv dgrad")
+    dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv3x3s2_wgrad(xd, dyd, dw, B, H, W, Cin, Cout)
+    assert_close(dw, wr.grad, tol, "conv wgrad")
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 12, 1, 16), (1, 10, 9, 3, 40), (2, 50, 40, 1, 256)])
+def test_conv_small_cin(ops, cd, B, H, W, Cin, Cout):
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64).float().double()
+    w = (torch.randn(3, 3, Cin, Cout, generator=g, dtype=torch.float64) * 0.3).float().double()
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g, dtype=torch.float64)
+    wr = w.clone().requires_grad_(True)
+    ref = om.conv2d_same_s2(x, wr)
+    (ref * rounded(dy, cd)).sum().backward()
+    out = torch.empty(B, Ho, Wo, Cout, dtype=cd, device=dev())
+    stats = torch.empty(2 * Cout, dtype=torch.float64, device=dev())
+    ops.conv_small_cin_fwd(x.float().to(dev()), w.float().to(dev()), out, B, H, W, Cin, Cout, stats)
+    assert_close(out, ref.detach(), TOL[cd], "conv1 fwd")
+    o64 = out.double().cpu().reshape(-1, Cout)
+    assert_close(stats[:Cout], o64.sum(0), 1e-5, "channel sums")
+    assert_close(stats[Cout:], (o64 * o64).sum(0), 1e-5, "channel sums of squares")
+    dw = torch.empty(3, 3, Cin, Cout, dtype=torch.float32, device=dev())
+    ops.conv_small_cin_wgrad(x.float().to(dev()), to_cd(dy, cd), dw, B, H, W, Cin, Cout)
+    assert_close(dw, wr.grad, 2e-5, "conv1 wgrad")
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("rows,C", [(700, 16), (1200, 256), (333, 64)])
+def test_batchnorm_relu6(ops, cd, rows, C):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g, dtype=torch.float64) * 2 + 0.5
+    gamma = torch.rand(C, generator=g, dtype=torch.float64) * 3 + 0.5
+    beta = torch.randn(C, generator=g, dtype=torch.float64) + 1
+    dy = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    xr = rounded(x, cd).requires_grad_(True)
+    gm, bt = gamma.float().double().requires_grad_(True), beta.float().double().requires_grad_(True)
+    y_bn, mean, var = om.batch_norm_train(xr.view(1, rows, 1, C), gm, bt)
+    y_ref = om.relu6(y_bn).view(rows, C)
+    (y_ref * rounded(dy, cd)).sum().backward()
+    xd = to_cd(x, cd)
+    x64 = xd.double()
+    stats = torch.cat([x64.sum(0), (x64 * x64).sum(0)])
+    mr = torch.empty(2 * C, dtype=torch.float32, device=dev())
+    mm = torch.zeros(C, dtype=torch.float32, device=dev())
+    mv = torch.ones(C, dtype=torch.float32, device=dev())
+    ops.bn_finalize(stats, rows, C, 1e-3, 0.99, mr, mm, mv)
+    assert_close(mr[:C], mean.detach(), 1e-5, "mean")
+    assert_close(mr[C:], 1 / torch.sqrt(var.detach() + 1e-3), 1e-5, "rstd")
+    assert_close(mm, 0.01 * mean.detach(), 1e-5, "moving mean")
+    assert_close(mv, 0.99 + 0.01 * var.detach() * rows / (rows - 1), 1e-5, "moving variance")
+    gd, bd = gamma.float().to(dev()), beta.float().to(dev())
+    y = torch.empty(rows, C, dtype=cd, device=dev())
+    ops.bn_relu6_apply(xd, mr, gd, bd, rows, C, y)
+    assert_close(y, y_ref.detach(), TOL[cd], "bn+relu6")
+    y2 = torch.empty_like(y)
+    ops.bn_relu6_infer(xd, mr[:C].contiguous(), (1 / mr[C:] ** 2 - 1e-3).contiguous(), gd, bd, 1e-3, rows, C, y2)
+    assert_close(y2, y_ref.detach(), TOL[cd] * 2, "bn infer")
+    # backward is fed the oracle's output so that the relu6 gate agrees at the boundaries
+    y_in = to_cd(y_ref.detach(), cd)
+    scratch = torch.empty(2 * C, dtype=torch.float64, device=dev())
+    dx = torch.empty_like(xd)
+    dg, db = torch.empty(C, device=dev()), torch.empty(C, device=dev())
+    ops.bn_relu6_bwd(to_cd(dy, cd), xd, y_in, mr, gd, rows, C, scratch, dx, dg, db)
+    tol = 1e-4 if cd == torch.float32 else 3e-2
+    assert_close(dg, gm.grad, tol, "dgamma")
+    assert_close(db, bt.grad, tol, "dbeta")
+    assert_close(dx, xr.grad, tol, "dx")
+
+
+# ------------------------------------------------------------------------------------------ PE / embedding
+@pytest.mark.parametrize("cd", DTYPES)
+def test_embedding_and_pe(ops, cd):
+    B, L, d, V = 3, 7, 32, 11
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(V, d, generator=g, dtype=torch.float64).float()
+    ids = torch.randint(0, V, (B, L), generator=g).to(torch.int32)
+    pe = om.make_positional_encoding(800, d)
+    xs = math.sqrt(d)
+    ref = table.double()[ids.long()] * xs + pe[:L].double()
+    y = torch.empty(B, L, d, dtype=cd, device=dev())
+    ops.embed_fwd(table.to(dev()), ids.to(dev()), pe.to(dev()), B, L, d, V, xs, 0.0, None, 0, y)
+    assert_close(y, ref, TOL[cd], "embedding")
+    dy = torch.randn(B, L, d, generator=g, dtype=torch.float64)
+    dt_ref = torch.zeros(V, d, dtype=torch.float64)
+    dt_ref.index_add_(0, ids.long().view(-1), (rounded(dy, cd) * xs).view(-1, d))
+    dtab = torch.zeros(V, d, dtype=torch.float32, device=dev())
+    ops.embed_bwd(to_cd(dy, cd), ids.to(dev()), B, L, d, V, xs, 0.0, None, 0, dtab)
+    assert_close(dtab, dt_ref, 1e-5, "embedding grad")
+    x = torch.randn(B, L, d, generator=g, dtype=torch.float64)
+    out = torch.empty(B, L, d, dtype=cd, device=dev())
+    ops.add_pe_dropout(to_cd(x, cd), pe.to(dev()), B, L, d, 1.0, 0.0, None, 0, out)
+    assert_close(out, rounded(x, cd) + pe[:L].double(), TOL[cd], "x + pe")
+    # dropout backward with the relu6 gate
+    yv = om.relu6(torch.randn(B, L, d, generator=g, dtype=torch.float64) * 4)
+    dx = torch.empty(B, L, d, dtype=cd, device=dev())
+    ops.dropout_bwd(to_cd(dy, cd), 1.0, 0.0, None, 0, to_cd(yv, cd), dx)
+    yr = rounded(yv, cd)
+    assert_close(dx, rounded(dy, cd) * ((yr > 0) & (yr < 6)).double(), 1e-6, "relu6 gate")
+
+
+# ------------------------------------------------------------------------------------------ CTC
+def _ctc_case(B, T, V, U, seed, ragged=True, repeats=True):
+    rng = np.random.default_rng(seed)
+    logits = rng.normal(size=(B, T, V)) * 2.0
+    labels = rng.integers(1, V - 1, size=(B, U)).astype(np.int32)
+    if repeats and U > 2:
+        labels[0, 1] = labels[0, 0]
+        labels[-1, -1] = labels[-1, -2]
+    if ragged:
+        llen = rng.integers(max(1, U // 2), U + 1, size=B).astype(np.int32)
+        llen[0] = U
+        tlen = rng.integers(min(T, 2 * U + 2), T + 1, size=B).astype(np.int32)
+        tlen[0] = T
+    else:
+        llen = np.full(B, U, np.int32)
+        tlen = np.full(B, T, np.int32)
+    for b in range(B):
+        labels[b, llen[b]:] = 0
+    return logits, labels, llen, tlen
+
+
+@pytest.mark.parametrize("B,T,V,U", [(3, 12, 7, 4), (4, 40, 30, 9), (2, 150, 50, 40), (5, 64, 4233, 20),
+                                     (2, 90, 101, 33), (2, 300, 60, 100), (1, 250, 40, 200), (2, 30, 12, 0)])
+def test_ctc_loss_and_grad_fp32(ops, B, T, V, U):
+    Ue = max(U, 1)
+    logits, labels, llen, tlen = _ctc_case(B, T, V, Ue, seed=B * 1000 + T + U)
+    if U == 0:
+        llen[:] = 0
+        labels[:] = 0
+    lt = torch.from_numpy(logits).float()
+    loss_ref, grad_ref = octc.ctc_loss_textbook(lt.double().numpy(), labels, llen, tlen, blank_index=-1)
+    ldl = (V + 7) // 8 * 8
+    buf = torch.zeros(B, T, ldl, dtype=torch.float32, device=dev())
+    buf[..., :V] = lt.to(dev())
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, Ue), dtype=torch.uint8, device=dev())
+    per = torch.empty(B, dtype=torch.float32, device=dev())
+    lab_d = torch.from_numpy(labels).to(dev())
+    ll_d, tl_d = torch.from_numpy(llen).to(dev()), torch.from_numpy(tlen).to(dev())
+    ops.ctc_loss_fwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, per, ws)
+    assert_close(per, loss_ref, 1e-5, "ctc loss")
+    grad = torch.full((B, T, ldl), float("nan"), dtype=torch.float32, device=dev())
+    gs = torch.tensor([0.5], dtype=torch.float32, device=dev())
+    ops.ctc_loss_bwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, gs, 2.0 / B, grad, ws)
+    assert_close(grad[..., :V], grad_ref / B, 1e-4, "ctc grad")
+    assert float(grad[..., V:].abs().max()) == 0.0 if ldl > V else True
+    for b in range(B):
+        assert float(grad[b, tlen[b]:].abs().max()) == 0.0 if tlen[b] < T else True
+
+
+def test_ctc_matches_brute_force(ops):
+    """Known answers: every alignment enumerated (tests/golden/ctc_kat.json)."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ctc_kat.json")))
+    for case in kat["cases"]:
+        logits = torch.tensor(case["logits"], dtype=torch.float32)
+        B, T, V = logits.shape
+        labels = torch.tensor(case["labels"], dtype=torch.int32)
+        U = labels.shape[1]
+        ldl = 8
+        buf = torch.zeros(B, T, ldl, device=dev())
+        buf[..., :V] = logits.to(dev())
+        ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev())
+        per = torch.empty(B, device=dev())
+        ops.ctc_loss_fwd(buf, ldl, labels.to(dev()), torch.tensor(case["label_length"], dtype=torch.int32).to(dev()),
+                         torch.tensor(case["logit_length"], dtype=torch.int32).to(dev()), B, T, V, U, V - 1, per, ws)
+        assert_close(per, torch.tensor(case["loss"]), 1e-5, "brute-force KAT")
+
+
+def test_ctc_infeasible_is_large_finite(ops):
+    B, T, V, U = 1, 3, 5, 4      # 4 labels cannot fit in 3 frames
+    buf = torch.zeros(B, T, 8, device=dev())
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev())
+    per = torch.empty(B, device=dev())
+    ops.ctc_loss_fwd(buf, 8, torch.tensor([[1, 2, 3, 1]], dtype=torch.int32).to(dev()),
+                     torch.tensor([4], dtype=torch.int32).to(dev()), torch.tensor([3], dtype=torch.int32).to(dev()),
+                     B, T, V, U, V - 1, per, ws)
+    assert torch.isfinite(per).all() and float(per[0]) > 1e20
+
+
+# ------------------------------------------------------------------------------------------ CE / argmax
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_ce_loss(ops, ls):
+    B, L, V = 4, 9, 53
+    g = torch.Generator().manual_seed(8)
+    logits = (torch.randn(B, L, V, generator=g, dtype=torch.float64) * 3).float()
+    tg = torch.randint(1, V, (B, L), generator=g).to(torch.int32)
+    tg[1, 5:] = 0
+    tg[3, 2:] = 0
+    lr = logits.double().requires_grad_(True)
+    y = F.one_hot(tg.long(), V).double()
+    if ls:
+        y = (1 - ls) * y + ls / V
+    rl = -(y * F.log_softmax(lr, -1)).sum(-1) * (tg != 0).double()
+    (rl.sum(-1).mean() * 0.7).backward()
+    ldl = 56
+    buf = torch.zeros(B, L, ldl, device=dev())
+    buf[..., :V] = logits.to(dev())
+    row_loss = torch.empty(B * L, device=dev())
+    lse = torch.empty(B * L, device=dev())
+    ops.ce_loss_fwd(buf, ldl, tg.to(dev()).view(-1), B * L, V, ls, row_loss, lse)
+    assert_close(row_loss, rl.detach().view(-1), 1e-5, "ce row loss")
+    grad = torch.full((B, L, ldl), float("nan"), device=dev())
+    gs = torch.tensor([0.7], device=dev())
+    ops.ce_loss_bwd(buf, ldl, tg.to(dev()).view(-1), B * L, V, ls, lse, gs, 1.0 / B, grad)
+    assert_close(grad[..., :V], lr.grad, 1e-4, "ce grad")
+    assert float(grad[..., V:].abs().max()) == 0.0
+    out = torch.empty(1, device=dev())
+    ops.group_sum(row_loss, 1, B * L, 1.0 / B, out)
+    assert_close(out, rl.detach().sum(-1).mean().view(1), 1e-5, "mean over batch of sums")
+
+
+def test_argmax_rows(ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(50, 4240, generator=g)
+    x[3, 7] = x[3, 4000] = 100.0          # first maximum wins
+    out = torch.empty(50, dtype=torch.int32, device=dev())
+    ops.argmax_rows(x.to(dev()), 4240, 50, 4233, out)
+    assert out.cpu().tolist() == x[:, :4233].argmax(-1).tolist()
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def test_clip_adam_and_shadows(ops):
+    from athena_amd import _lib
+    g = torch.Generator().manual_seed(6)
+    sizes = [64 * 3, 64 * 70, 64, 64 * 130]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    p0 = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g) * torch.tensor(np.repeat([0.01, 5.0, 1.0, 0.5], sizes)).float()
+    m0 = torch.randn(n, generator=g) * 0.1
+    v0 = torch.rand(n, generator=g) * 0.1
+    cfgd = dict(d_model=256, warmup_steps=10, k=1.0, decay_steps=4, decay_rate=0.5)
+    for step in (0, 7):
+        p_ref, m_ref, v_ref = p0.double().clone(), m0.double().clone(), v0.double().clone()
+        lr = om.warmup_lr(step, **cfgd)
+        for i in range(len(sizes)):
+            sl = slice(int(offs[i]), int(offs[i + 1]))
+            gg = om.clip_by_norm(gr.double()[sl] * 0.5, 3.0)
+            om.adam_update(p_ref[sl], gg, m_ref[sl], v_ref[sl], step, lr)
+        p, m, v = p0.to(dev()), m0.to(dev()), v0.to(dev())
+        st = torch.tensor([step], dtype=torch.int64, device=dev())
+        norms = torch.empty(len(sizes), device=dev())
+        lr_out = torch.empty(1, device=dev())
+        cfg = _lib.AdamCfg(0.9, 0.999, 1e-7, 3.0, 256.0, 10.0, 1.0, 4.0, 0.5, 0.5)
+        ops.clip_adam_step(p, gr.to(dev()), m, v, torch.from_numpy(offs).to(dev()), len(sizes), norms, st, cfg, lr_out)
+        assert int(st.item()) == step + 1
+        assert_close(lr_out, torch.tensor([lr]), 1e-5, "lr")
+        assert_close(m, m_ref, 1e-5, "m")
+        assert_close(v, v_ref, 1e-5, "v")
+        assert_close(p, p_ref, 1e-5, "param")
+
+
+def test_refresh_shadows(ops):
+    from athena_amd.runtime import ParamStore, glorot_uniform
+    st = ParamStore(torch.bfloat16, device=dev())
+    st.register("a", (40, 72), glorot_uniform(40, 72), matrix=(40, 72))
+    st.register("b", (7,), glorot_uniform(7, 7))
+    st.register("c", (3, 3, 8, 13), glorot_uniform(72, 13), matrix=(72, 13))
+    st.finalize(seed=3)
+    st.refresh_shadows()
+    for name in ("a", "c"):
+        r, c = st.by_name[name].matrix
+        w = st.view(name).reshape(r, c)
+        s, s_t = st.shadow_views(name)
+        assert torch.equal(s[:, :c], w.to(torch.bfloat16))
+        assert torch.equal(s_t[:, :r], w.t().to(torch.bfloat16))
+        assert float(s[:, c:].abs().sum()) == 0.0 and float(s_t[:, r:].abs().sum()) == 0.0

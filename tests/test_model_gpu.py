@@ -1,0 +1,148 @@
+"""End-to-end parity of the training step against the CPU oracle on identical weights and inputs.
+
+fp32 precision mode: losses within 1e-5 relative, every gradient tensor within 1e-4 (relative to
+its largest element), parameters after optimizer steps within 1e-5.  bf16 mode: logits within
+1e-2 absolute of the fp32 oracle.
+"""
+import copy
+
+import pytest
+import torch
+
+from oracle import model as om
+from tests.modelutil import SMALL, TINY, DataDescriptions, oracle_cfg
+from tests.util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def build(case, precision, full_length=False):
+    from athena_amd import MtlTransformerCtc
+    dd = DataDescriptions(case["vocab"], case["feat"])
+    model = MtlTransformerCtc(dd, copy.deepcopy(case["mc"]), precision=precision, seed=1)
+    V = case["vocab"] + 1
+    samples = om.make_samples(case["B"], case["T"], case["feat"], V, case["U"], seed=5, full_length=full_length)
+    return model, samples, oracle_cfg(case["mc"], V, case["feat"])
+
+
+def oracle_params(model, dtype=torch.float64):
+    p = {k: v.to(dtype) for k, v in model.store.state_dict().items()}
+    for k, v in p.items():
+        if not k.endswith(om.TRAINABLE_SKIP):
+            v.requires_grad_(True)
+    return p
+
+
+@pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
+def test_fp32_forward_loss_backward(case):
+    model, samples, ocfg = build(case, "fp32")
+    p = oracle_params(model)
+    s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in samples.items()}
+    att_ref, ctc_ref, _ = om.forward(p, s64, ocfg, training=True)
+    loss_ref, ce_ref, ctcl_ref = om.get_loss(att_ref, ctc_ref, s64, ocfg)
+    loss_ref.backward()
+
+    ds = model.prepare_samples(samples)
+    att, ctc = model(ds, training=True)
+    assert tuple(att.shape) == tuple(att_ref.shape) and tuple(ctc.shape) == tuple(ctc_ref.shape)
+    assert_close(att, att_ref.detach(), 2e-5, "attention logits")
+    assert_close(ctc, ctc_ref.detach(), 2e-5, "ctc logits")
+    loss, metrics = model.get_loss((att, ctc), ds, training=True)
+    assert_close(loss, loss_ref.detach(), 1e-5, "total loss")
+    loss.backward()
+    worst = ("", 0.0)
+    for name, t in p.items():
+        if name.endswith(om.TRAINABLE_SKIP):
+            continue
+        g = model.store.grad_view(name)
+        e = rel_err(g, t.grad if t.grad is not None else torch.zeros_like(t))
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] <= 1e-4, "gradient of %s: relative error %.3e" % worst
+    # metrics: same counts as the oracle's host restatement
+    ll = om.compute_logit_length(samples["input_length"])
+    cref = om.ctc_accuracy_counts(ctc_ref.detach(), samples, ll)
+    aref = om.seq2seq_accuracy_counts(att_ref.detach(), samples, ocfg["num_class"] - 1)
+    if cref is not None:
+        assert abs(float(metrics["CTCAccuracy"]) - (1 - cref[0] / cref[1])) < 1e-6
+    assert abs(float(metrics["Accuracy"]) - (1 - aref[0] / aref[1])) < 1e-6
+
+
+def test_fp32_training_steps_match_oracle():
+    from athena_amd import BaseSolver, WarmUpAdam
+    case = TINY
+    model, samples, ocfg = build(case, "fp32")
+    p = oracle_params(model)
+    s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in samples.items()}
+    opt_cfg = dict(d_model=32, warmup_steps=3, k=1.0, decay_steps=100000, decay_rate=1.0)
+    opt = WarmUpAdam(dict(opt_cfg))
+    solver = BaseSolver(model, opt, config={"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": False})
+    st = {"iterations": 0, "m": {}, "v": {}}
+    ds = model.prepare_samples(samples)
+    for step in range(4):
+        lref = om.train_step(p, st, s64, ocfg, {"clip_norm": 0.5}, opt_cfg)[0]
+        loss, _ = solver.train_step(ds)
+        assert_close(loss, lref, 2e-5, "loss at step %d" % step)
+    assert opt.iterations == 4
+    state = model.store.state_dict()
+    worst = max((rel_err(state[k], v.detach()), k) for k, v in p.items())
+    assert worst[0] <= 5e-5, "parameter %s after 4 steps: %.3e" % (worst[1], worst[0])
+
+
+@pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
+def test_bf16_logits_within_1e2_of_fp32_oracle(case):
+    model, samples, ocfg = build(case, "bf16")
+    p = oracle_params(model, torch.float32)
+    att_ref, ctc_ref, _ = om.forward(p, samples, ocfg, training=True)
+    ds = model.prepare_samples(samples)
+    att, ctc = model(ds, training=True)
+    assert float((att.float().cpu() - att_ref.detach()).abs().max()) <= 1e-2
+    assert float((ctc.float().cpu() - ctc_ref.detach()).abs().max()) <= 1e-2
+    loss, _ = model.get_loss((att, ctc), ds, training=True)
+    loss_ref = om.get_loss(att_ref, ctc_ref, samples, ocfg)[0]
+    assert_close(loss, loss_ref.detach(), 2e-3, "bf16 loss")
+    loss.backward()
+    loss_ref.backward()
+    # gradients: direction agrees with the fp32 oracle (cosine over all parameters)
+    num = den1 = den2 = 0.0
+    for name, t in p.items():
+        if name.endswith(om.TRAINABLE_SKIP) or t.grad is None:
+            continue
+        g = model.store.grad_view(name).double().cpu().view(-1)
+        r = t.grad.double().view(-1)
+        num += float(g @ r)
+        den1 += float(g @ g)
+        den2 += float(r @ r)
+    cos = num / (den1 ** 0.5 * den2 ** 0.5)
+    assert cos > 0.995, cos
+
+
+def test_eval_mode_uses_moving_statistics():
+    model, samples, ocfg = build(TINY, "fp32")
+    ds = model.prepare_samples(samples)
+    model(ds, training=True)          # updates the moving statistics once
+    p = oracle_params(model)
+    s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in samples.items()}
+    att_ref, ctc_ref, _ = om.forward(p, s64, ocfg, training=False)
+    with torch.no_grad():
+        att, ctc = model(ds, training=False)
+    assert_close(att, att_ref.detach(), 5e-5, "eval attention logits")
+    assert_close(ctc, ctc_ref.detach(), 5e-5, "eval ctc logits")
+
+
+def test_dropout_training_runs_and_is_reproducible():
+    import copy as cp
+    case = cp.deepcopy(TINY)
+    case["mc"]["model_config"]["rate"] = 0.1
+    model, samples, _ = build(case, "bf16")
+    ds = model.prepare_samples(samples)
+    a1, c1 = model(ds, training=True)
+    a2, c2 = model(ds, training=True)      # same rng state: same masks
+    assert torch.equal(a1, a2) and torch.equal(c1, c2)
+    loss, _ = model.get_loss((a1, c1), ds, training=True)
+    loss.backward()
+    assert torch.isfinite(model.store.grads).all()
+    from athena_amd import ops
+    ops.advance_rng(model.store.rng_state)
+    a3, _ = model(ds, training=True)
+    assert not torch.equal(a1, a3)
