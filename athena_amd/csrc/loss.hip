@@ -238,7 +238,8 @@ __global__ __launch_bounds__(128) void ctc_lattice_kernel(const int32_t* __restr
         // combine across lanes (at most two lanes hold a final state)
         float fm = wave_max(fin);
         float fs = wave_sum(fin <= CTC_LOGZERO ? 0.f : __expf(fin - fm));
-        if (lane == 0) loss[b] = -(cum + fm + __logf(fs));
+        // no alignment fits: report the finite log-zero instead of -log(0)
+        if (lane == 0) loss[b] = fs > 0.f ? -(cum + fm + __logf(fs)) : -CTC_LOGZERO;
     } else {
         // ---------------- beta: beta[len-1][s] = 0 for final states; beta[t][s] = lse over successors
         // s' in {s, s+1, s+2(skip)} of beta[t+1][s'] + em[t+1][s']

@@ -359,7 +359,8 @@ extern "C" int athena_bn_relu6_infer(const void* x, const float* moving_mean, co
 #define BN_ROWS_PER_BLOCK 512
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            const T* __restrict__ y,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
                                                             const float* __restrict__ mean_rstd, long rows, int C,
                                                             double* __restrict__ scratch) {
     __shared__ float red[256][17];
@@ -373,20 +374,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const long r1 = min(rows, r0 + BN_ROWS_PER_BLOCK);
     if (chunk < cpr && slot < slots) {
         const int c0 = chunk * 8;
-        float mu[8], rs[8];
+        float mu[8], rs[8], ga[8], be[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { mu[i] = mean_rstd[c0 + i]; rs[i] = mean_rstd[C + c0 + i]; }
+        for (int i = 0; i < 8; ++i) {
+            mu[i] = mean_rstd[c0 + i]; rs[i] = mean_rstd[C + c0 + i];
+            ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
+        }
         for (long r = r0 + slot; r < r1; r += slots) {
             const long o = r * C + c0;
-            float dv[8], xv[8], yv[8];
+            float dv[8], xv[8];
             Vec8<T>::load(dy + o, dv);
             Vec8<T>::load(x + o, xv);
-            Vec8<T>::load(y + o, yv);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float g = (yv[i] > 0.f && yv[i] < 6.f) ? dv[i] : 0.f;
+                const float xh = (xv[i] - mu[i]) * rs[i];
+                const float yb = xh * ga[i] + be[i];        // the relu6 gate is recomputed, not read
+                float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
                 a1[i] += g;
-                a2[i] += g * (xv[i] - mu[i]) * rs[i];
+                a2[i] += g * xh;
             }
         }
     }
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const T* __restrict__ y,
+                                                           const float* __restrict__ beta,
                                                            const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ scratch, long rows, int C,
@@ -420,17 +425,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const float inv_n = 1.f / (float)rows;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nchunks; e += (long)gridDim.x * blockDim.x) {
         const int c0 = (int)(e % cpr) * 8;
-        float dv[8], xv[8], yv[8], o[8];
+        float dv[8], xv[8], o[8];
         Vec8<T>::load(dy + e * 8, dv);
         Vec8<T>::load(x + e * 8, xv);
-        Vec8<T>::load(y + e * 8, yv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c0 + i;
             const float mu = mean_rstd[c], rs = mean_rstd[C + c];
             const float sb = (float)scratch[c], sg = (float)scratch[C + c];
-            const float g = (yv[i] > 0.f && yv[i] < 6.f) ? dv[i] : 0.f;
             const float xh = (xv[i] - mu) * rs;
+            const float yb = xh * gamma[c] + beta[c];
+            const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
             o[i] = gamma[c] * rs * (g - sb * inv_n - xh * sg * inv_n);
         }
         Vec8<T>::store(dx + e * 8, o);
@@ -443,14 +448,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const void* y, const float* mean_rstd,
-                                   const float* gamma, long rows, int C, int dtype, double* scratch, void* dx,
+extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const float* mean_rstd, const float* gamma,
+                                   const float* beta, long rows, int C, int dtype, double* scratch, void* dx,
                                    float* dgamma, float* dbeta, athena_stream_t stream) {
-    ATHENA_REQUIRE(dy && x && y && mean_rstd && gamma && scratch && dx && dgamma && dbeta && rows > 0 && C > 0,
+    ATHENA_REQUIRE(dy && x && beta && mean_rstd && gamma && scratch && dx && dgamma && dbeta && rows > 0 && C > 0,
                    ATHENA_E_SHAPE, "athena_bn_relu6_bwd: bad arguments");
     ATHENA_REQUIRE(C % 8 == 0, ATHENA_E_ALIGN, "athena_bn_relu6_bwd: C %% 8 required");
     const int cpr = C / 8;
-    ATHENA_REQUIRE(cpr >= 256 ? (cpr % 256 == 0) : (256 % cpr == 0 || true), ATHENA_E_SHAPE, "athena_bn_relu6_bwd: C");
     hipStream_t s = (hipStream_t)stream;
     ATHENA_REQUIRE(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * C, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_bn_relu6_bwd: memset failed");
     const int cpb = cpr < 256 ? cpr : 256;
@@ -459,11 +463,11 @@ extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const void* y,
     long blocks = (nchunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (dtype == ATHENA_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, mean_rstd, rows, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, mean_rstd, gamma, scratch, rows, C, (bf16_t*)dx, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean_rstd, rows, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, beta, mean_rstd, gamma, scratch, rows, C, (bf16_t*)dx, dgamma, dbeta);
     } else if (dtype == ATHENA_F32) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)y, mean_rstd, rows, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, (const float*)y, mean_rstd, gamma, scratch, rows, C, (float*)dx, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, beta, mean_rstd, rows, C, scratch);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, beta, mean_rstd, gamma, scratch, rows, C, (float*)dx, dgamma, dbeta);
     } else {
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6_bwd: dtype");
     }

@@ -349,14 +349,14 @@ class XNetFn(torch.autograd.Function):
         da2 = lin_bwd_x(dpre, M, net.dense, d)
         scratch = torch.empty(2 * C, dtype=torch.float64, device=dev)
         dc2 = torch.empty_like(c2)
-        ops.bn_relu6_bwd(da2, c2, a2, mr2, net.bn2.gamma, rows2, C, scratch, dc2, net.bn2.gamma.grad,
+        ops.bn_relu6_bwd(da2, c2, mr2, net.bn2.gamma, net.bn2.beta, rows2, C, scratch, dc2, net.bn2.gamma.grad,
                          net.bn2.beta.grad)
         ops.conv3x3s2_wgrad(a1, dc2, net.conv2.kernel.grad, B, T1, F1, C, C)
         da1 = torch.empty_like(a1)
         w_hwio = net.conv2.shadow if c2.dtype == torch.bfloat16 else net.conv2.kernel
         ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
         dc1 = torch.empty_like(c1)
-        ops.bn_relu6_bwd(da1, c1, a1, mr1, net.bn1.gamma, rows1, C, scratch, dc1, net.bn1.gamma.grad,
+        ops.bn_relu6_bwd(da1, c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, scratch, dc1, net.bn1.gamma.grad,
                          net.bn1.beta.grad)
         ops.conv_small_cin_wgrad(x0, dc1, net.conv1.kernel.grad, B, T, Fd, nc, C)
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)

@@ -228,12 +228,12 @@ def bn_relu6_infer(x, moving_mean, moving_var, gamma, beta, eps, rows, C, y):
                                          eps, rows, C, dt(x), _ptr(y), _stream()), "athena_bn_relu6_infer")
 
 
-def bn_relu6_bwd(dy, x, y, mean_rstd, gamma, rows, C, scratch, dx, dgamma, dbeta):
+def bn_relu6_bwd(dy, x, mean_rstd, gamma, beta, rows, C, scratch, dx, dgamma, dbeta):
     lib = _lib.load()
-    if any(t.numel() != rows * C for t in (dy, x, y, dx)) or scratch.dtype != torch.float64 or \
+    if any(t.numel() != rows * C for t in (dy, x, dx)) or scratch.dtype != torch.float64 or \
             scratch.numel() < 2 * C:
         raise RuntimeError("athena_amd.bn_relu6_bwd: bad operands")
-    _lib.check(lib.athena_bn_relu6_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(mean_rstd), _ptr(gamma), rows, C, dt(x),
+    _lib.check(lib.athena_bn_relu6_bwd(_ptr(dy), _ptr(x), _ptr(mean_rstd), _ptr(gamma), _ptr(beta), rows, C, dt(x),
                                        _ptr(scratch), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
                "athena_bn_relu6_bwd")
 

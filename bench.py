@@ -1,0 +1,240 @@
+"""Throughput of the hybrid attention/CTC training step on MI355X.
+
+python bench.py --gpus N --steps K --warmup W     (N > 1: launched by torch.distributed.run)
+
+One step = forward + backward + per-tensor clip + Adam of MtlTransformerCtc on one synthetic
+batch (per-rank batch fixed, so N ranks process N batches per step: weak scaling).  Prints ONE
+JSON line on rank 0: audio-seconds per second over all ranks, plus the roofline figures of the
+dominant kernel (measured with HIP events on the launch stream) and the CPU oracle's rate.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAME_SHIFT_S = 0.010      # 10 ms fbank frame shift
+
+WORKLOADS = {
+    # AISHELL-sized MTL Transformer-CTC: 12 enc / 6 dec, d=256, 4 heads, 4233 classes, batch 32, T=1000, 80-dim
+    "aishell_b32_t1000": dict(B=32, T=1000, feat=80, vocab=4232, U=32, d_model=256, num_filters=256, heads=4,
+                              enc=12, dec=6, dff=1024, rate=0.1, opt=dict(d_model=256, warmup_steps=25000, k=1.0,
+                                                                          decay_steps=100000000, decay_rate=0.1),
+                              clip_norm=100.0),
+    # TIMIT recipe (the reference's CPU-runnable case)
+    "timit_b16_t500": dict(B=16, T=500, feat=40, vocab=49, U=40, d_model=256, num_filters=256, heads=8, enc=9,
+                           dec=3, dff=1024, rate=0.2, opt=dict(d_model=256, warmup_steps=4000, k=1.0),
+                           clip_norm=100.0),
+    "tiny": dict(B=4, T=64, feat=16, vocab=30, U=5, d_model=64, num_filters=32, heads=2, enc=2, dec=1, dff=128,
+                 rate=0.1, opt=dict(d_model=64, warmup_steps=10, k=1.0), clip_norm=100.0),
+}
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def build(wl, precision, seed):
+    from athena_amd import BaseSolver, HorovodSolver, MtlTransformerCtc, WarmUpAdam
+    from tests.modelutil import DataDescriptions, model_config
+    mc = model_config(wl["d_model"], wl["num_filters"], wl["heads"], wl["enc"], wl["dec"], wl["dff"], wl["rate"])
+    model = MtlTransformerCtc(DataDescriptions(wl["vocab"], wl["feat"]), mc, precision=precision, seed=seed)
+    opt = WarmUpAdam(dict(wl["opt"]))
+    cfg = {"clip_norm": wl["clip_norm"], "log_interval": 10 ** 9, "enable_tf_function": True}
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    solver = (HorovodSolver if world > 1 else BaseSolver)(model, opt, config=cfg)
+    return model, opt, solver, mc
+
+
+def gemm_flops_per_step(wl):
+    """Algorithmic FLOPs of all Dense/Conv2D contractions of one training step (forward x 3)."""
+    B, T, Fd = wl["B"], wl["T"], wl["feat"]
+    C, d, dff, V, U = wl["num_filters"], wl["d_model"], wl["dff"], wl["vocab"] + 1, wl["U"]
+    T1, F1 = (T + 1) // 2, (Fd + 1) // 2
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    L = U + 1
+    conv2 = 2 * 9 * C * C * T2 * F2
+    xdense = 2 * F2 * C * d * T2
+    enc = wl["enc"] * (8 * T2 * d * d + 4 * T2 * d * dff)
+    dec = wl["dec"] * (8 * L * d * d + 4 * L * d * d + 4 * T2 * d * d + 4 * L * d * dff)
+    heads = 2 * L * d * V + 2 * T2 * d * V
+    return 3.0 * B * (conv2 + xdense + enc + dec + heads)
+
+
+def ctc_bytes(wl):
+    """Algorithmic HBM bytes of the CTC loss per step: logits read twice, gradient written once."""
+    T2 = (((wl["T"] + 1) // 2) + 1) // 2
+    V = wl["vocab"] + 1
+    S = 2 * wl["U"] + 1
+    return wl["B"] * T2 * V * 4 * 3 + wl["B"] * T2 * S * 4 * 2
+
+
+class KernelTimer:
+    """HIP-event timing of selected C-ABI entry points on the launch stream."""
+
+    def __init__(self, names):
+        from athena_amd import _lib
+        self.lib = _lib.load()
+        self.names = names
+        self.pairs = {n: [] for n in names}
+        self._orig = {}
+
+    def __enter__(self):
+        from athena_amd import ops
+        self.ops = ops
+        for n in self.names:
+            fn = getattr(ops, n)
+            self._orig[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n, **k):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _fn(*a, **k)
+                e1.record()
+                self.pairs[_n].append((e0, e1))
+                return r
+            setattr(ops, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self._orig.items():
+            setattr(self.ops, n, fn)
+
+    def total_ms(self, name):
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.pairs[name]), len(self.pairs[name])
+
+
+def cpu_baseline(wl, model, mc, seconds_budget=30.0):
+    """The CPU oracle (torch-CPU fp32 restatement of the same step) on a bounded sample."""
+    from oracle import model as om
+    from tests.modelutil import oracle_cfg
+    V = wl["vocab"] + 1
+    cores = os.cpu_count() or 1
+    cores = min(cores, 16)
+    torch.set_num_threads(cores)
+    Bs = min(wl["B"], 4)
+    ocfg = oracle_cfg(mc, V, wl["feat"])
+    p = {k: v.clone() for k, v in model.store.state_dict().items()}
+    for k, v in p.items():
+        if not k.endswith(om.TRAINABLE_SKIP):
+            v.requires_grad_(True)
+    s = om.make_samples(Bs, wl["T"], wl["feat"], V, wl["U"], seed=1, full_length=True)
+    st = {"iterations": 0, "m": {}, "v": {}}
+    times = []
+    t_start = time.time()
+    for i in range(3):
+        t0 = time.time()
+        om.train_step(p, st, s, ocfg, {"clip_norm": wl["clip_norm"]}, dict(wl["opt"]))
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": Bs * wl["T"] * FRAME_SHIFT_S / t, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": "%d of %d utterances per step (T=%d), %d steps, fastest after warm-up; torch-CPU fp32 "
+                      "oracle of the same training step" % (Bs, wl["B"], wl["T"], len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="aishell_b32_t1000")
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")
+    wl = WORKLOADS[args.workload]
+
+    from oracle import model as om      # synthetic batch generator only (inputs, not the measured path)
+    model, opt, solver, mc = build(wl, args.precision, seed=1)
+    if args.no_graph:
+        solver.hparams.enable_tf_function = False
+    V = wl["vocab"] + 1
+    samples = om.make_samples(wl["B"], wl["T"], wl["feat"], V, wl["U"], seed=1 + rank, full_length=True)
+    ds = model.prepare_samples(samples)          # resident in HBM before the timed region
+    if world > 1:
+        solver.broadcast_variables()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, _ = solver.train_step(ds)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = solver.train_step(ds)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+
+    # per-kernel timing pass (eager, HIP events around the entry points), rank 0 only
+    roof = ctc_roof = None
+    if rank == 0:
+        was = solver.hparams.enable_tf_function
+        solver.hparams.enable_tf_function = False
+        names = ["gemm", "conv3x3s2_fwd", "conv3x3s2_dgrad", "conv3x3s2_wgrad", "ctc_loss_fwd", "ctc_loss_bwd"]
+        nrep = 3
+        solver.train_step(ds)
+        with KernelTimer(names) as kt:
+            for _ in range(nrep):
+                solver.train_step(ds)
+        solver.hparams.enable_tf_function = was
+        g_ms = sum(kt.total_ms(n)[0] for n in names[:4])
+        g_calls = sum(kt.total_ms(n)[1] for n in names[:4])
+        flops = gemm_flops_per_step(wl) * nrep
+        ach = flops / (g_ms * 1e-3) / 1e12
+        roof = {"kernel": "gemm_mfma_kernel (Dense + implicit-GEMM Conv2D, all launches of a step)",
+                "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep}
+        c_ms = kt.total_ms("ctc_loss_fwd")[0] + kt.total_ms("ctc_loss_bwd")[0]
+        cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
+        ctc_roof = {"kernel": "ctc_prep + ctc_lattice + ctc_grad", "bound": "hbm", "achieved": cb,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS, "traffic": None,
+                    "ms_per_step": c_ms / nrep}
+
+    if rank == 0:
+        audio_s = wl["B"] * wl["T"] * FRAME_SHIFT_S * world * args.steps
+        out = {
+            "metric": "audio-sec/sec fwd+bwd, Transformer-CTC AISHELL b32 T=1000",
+            "value": audio_s / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": args.workload, "per_gpu_batch": wl["B"], "global_batch": wl["B"] * world,
+                       "frames": wl["T"], "fbank_dim": wl["feat"], "classes": V, "parallelism": "dp%d" % world,
+                       "hip_graph": bool(solver.hparams.enable_tf_function), "dropout": wl["rate"]},
+            "final_loss": final_loss,
+            "roofline": roof, "roofline_ctc": ctc_roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, model, mc)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
