@@ -85,17 +85,21 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ---------------------------------------------------------------- activations
 __device__ __forceinline__ float relu6f(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
-// tanh-form GELU and its derivative
+// tanh-form GELU and its derivative; tanh(u) = 1 - 2/(exp(2u)+1) on the fast exp/divide units
+__device__ __forceinline__ float fast_tanh_f(float u) {
+    const float e = __expf(2.f * u);          // inf for large u -> 1 - 0; 0 for very negative u -> -1
+    return 1.f - __fdividef(2.f, e + 1.f);
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float c = 0.7978845608028654f;
     float u = c * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.f + tanhf(u));
+    return 0.5f * x * (1.f + fast_tanh_f(u));
 }
 __device__ __forceinline__ float dgelu_tanh_f(float x) {
     const float c = 0.7978845608028654f;
     float x2 = x * x;
     float u = c * (x + 0.044715f * x * x2);
-    float t = tanhf(u);
+    float t = fast_tanh_f(u);
     float du = c * (1.f + 3.f * 0.044715f * x2);
     return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
 }
@@ -107,11 +111,14 @@ __device__ __forceinline__ uint64_t rng_key(const uint64_t* state, uint32_t site
     return k;
 }
 __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
-    uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 32);
+    // 32-bit integer hash of (key, element index): a handful of VALU ops per element
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u;
+    h ^= (uint32_t)key;
+    h += (uint32_t)(key >> 32);
+    h ^= h >> 16; h *= 0x7FEB352Du;
+    h ^= h >> 15; h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
 }
 // returns the multiplier: 0 (dropped) or 1/(1-p)
 __device__ __forceinline__ float dropout_mult(uint64_t key, uint64_t idx, uint32_t thresh, float scale) {

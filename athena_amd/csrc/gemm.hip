@@ -69,7 +69,6 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     p.A = d->A;
     p.B = d->B;
     p.amap.ld = d->lda;
-    p.amap.seg_stride = 0;
     p.M = d->M;
     p.N = d->N;
     p.nseg = 1;
@@ -214,30 +213,30 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_wgrad: memset failed");
     const int rows = B * Ho * Wo;
     // dw[tap][ci][co] = sum_r in(r, tap)[ci] * dout[r][co]: A transposed through the gather, B = dout [K][N]
-    int split = gemm_auto_split(Cin, Cout, rows, dtype);
-    // nine launches share the chip
-    split = (split + 8) / 9;
+    // the nine taps are nine independent GEMMs stacked in grid.z; split the long contraction so
+    // that taps x splits x output tiles fill the chip
+    int split = (gemm_auto_split(Cin, Cout, rows, dtype) + 8) / 9;
     if (split < 1) split = 1;
-    for (int tap = 0; tap < 9; ++tap) {
-        GemmProblem<ConvFwdRows> p;
-        memset(&p, 0, sizeof(p));
-        p.A = in;
-        p.B = dout;
-        p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
-        p.M = Cin;
-        p.N = Cout;
-        p.nseg = 1;
-        p.kseg = rows;
-        p.ldb = Cout;
-        p.seg_base = tap;
-        p.split_k = split;
-        p.epi.C = dw_hwio + (long)tap * Cin * Cout;
-        p.epi.ldc = Cout;
-        p.epi.c_dtype = ATHENA_F32;
-        p.epi.alpha = 1.f;
-        p.epi.atomic = 1;
-        rc = launch_gemm(p, dtype, true, false, (hipStream_t)stream);
-        if (rc) return rc;
-    }
+    GemmProblem<ConvFwdRows> p;
+    memset(&p, 0, sizeof(p));
+    p.A = in;
+    p.B = dout;
+    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
+    p.M = Cin;
+    p.N = Cout;
+    p.nseg = 1;
+    p.kseg = rows;
+    p.ldb = Cout;
+    p.seg_base = 0;
+    p.split_k = split;
+    p.zbatch = 9;
+    p.c_batch_stride = (long)Cin * Cout;
+    p.epi.C = dw_hwio;
+    p.epi.ldc = Cout;
+    p.epi.c_dtype = ATHENA_F32;
+    p.epi.alpha = 1.f;
+    p.epi.atomic = 1;
+    rc = launch_gemm(p, dtype, true, false, (hipStream_t)stream);
+    if (rc) return rc;
     return ATHENA_OK;
 }

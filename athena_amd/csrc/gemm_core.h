@@ -4,8 +4,8 @@
 //
 // Two cores with the same problem description:
 //   * gemm_mfma_kernel  : bf16 operands, fp32 accumulate on the matrix cores
-//                         (v_mfma_f32_16x16x32_bf16), 128x128x32 tiles staged through LDS,
-//                         4 waves of 64 lanes, each owning a 64x64 sub-tile (4x4 MFMA tiles).
+//                         (v_mfma_f32_16x16x32_bf16), tiles staged through a double-buffered LDS,
+//                         4 waves of 64 lanes, each owning a quarter of the output tile.
 //   * gemm_valu_kernel  : fp32 operands, fp32 FMA on the vector ALUs, 64x64x16 tiles; the
 //                         exact-arithmetic path used by the fp32 precision mode.
 //
@@ -34,39 +34,91 @@ struct Epilogue {
     uint32_t rng_site;
 };
 
-__device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float acc, uint64_t key) {
+__device__ __forceinline__ float epilogue_value(const Epilogue& e, long ci, long ai, int n, float acc, uint64_t key,
+                                                float* pre_out) {
     float v = acc * e.alpha;
-    const long ci = (long)m * e.ldc + n;
-    if (e.atomic) {
-        atomicAdd((float*)e.C + ci, v);
-        return;
-    }
     if (e.bias) v += e.bias[n];
-    if (e.C_pre) store_from_f32(e.C_pre, ci, e.c_dtype, v);
+    *pre_out = v;
     switch (e.act) {
         case ATHENA_ACT_RELU6: v = relu6f(v); break;
         case ATHENA_ACT_GELU: v = gelu_tanh_f(v); break;
-        case ATHENA_ACT_MUL_DGELU: {
-            float h = load_as_f32(e.aux, (long)m * e.ldaux + n, e.aux_dtype);
-            v *= dgelu_tanh_f(h);
-        } break;
+        case ATHENA_ACT_MUL_DGELU: v *= dgelu_tanh_f(load_as_f32(e.aux, ai, e.aux_dtype)); break;
         case ATHENA_ACT_MUL_DRELU6: {
-            float y = load_as_f32(e.aux, (long)m * e.ldaux + n, e.aux_dtype);
+            float y = load_as_f32(e.aux, ai, e.aux_dtype);
             v = (y > 0.f && y < 6.f) ? v : 0.f;
         } break;
         default: break;
     }
     if (e.drop_thresh) v *= dropout_mult(key, (uint64_t)ci, e.drop_thresh, e.drop_scale);
+    return v;
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float acc, uint64_t key,
+                                               long coff = 0) {
+    const long ci = (long)m * e.ldc + n;
+    if (e.atomic) {
+        atomicAdd((float*)e.C + coff + ci, acc * e.alpha);
+        return;
+    }
+    float pre;
+    float v = epilogue_value(e, ci, (long)m * e.ldaux + n, n, acc, key, &pre);
+    if (e.C_pre) store_from_f32(e.C_pre, ci, e.c_dtype, pre);
     if (e.accum) v += load_as_f32(e.C, ci, e.c_dtype);
     store_from_f32(e.C, ci, e.c_dtype, v);
 }
 
+// four consecutive columns n..n+3 of output row m (caller guarantees n + 3 < N)
+__device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n, f32x4_t acc, uint64_t key,
+                                                bool vec_ok, long coff = 0) {
+    const long ci = (long)m * e.ldc + n;
+    if (e.atomic) {
+        float* c = (float*)e.C + coff + ci;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(c + r, acc[r] * e.alpha);
+        return;
+    }
+    if (!vec_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epilogue_store(e, m, n + r, acc[r], key);
+        return;
+    }
+    const long ai = (long)m * e.ldaux + n;
+    float v[4], pre[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = epilogue_value(e, ci + r, ai + r, n + r, acc[r], key, &pre[r]);
+    if (e.c_dtype == ATHENA_BF16) {
+        bf16_t* c = (bf16_t*)e.C + ci;
+        if (e.C_pre) {
+            bf16x4_t pv = {(bf16_t)pre[0], (bf16_t)pre[1], (bf16_t)pre[2], (bf16_t)pre[3]};
+            *(bf16x4_t*)((bf16_t*)e.C_pre + ci) = pv;
+        }
+        if (e.accum) {
+            bf16x4_t old = *(const bf16x4_t*)c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+        }
+        bf16x4_t o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *(bf16x4_t*)c = o;
+    } else {
+        float* c = (float*)e.C + ci;
+        if (e.C_pre) *(float4*)((float*)e.C_pre + ci) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+        if (e.accum) {
+            float4 old = *(const float4*)c;
+            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        }
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ------------------------------------------------------------------ row maps for the A operand
-// off(r, seg) = element offset of row r of segment seg, or -1 when the row is all zeros.
+// prep(r) decodes row r once; off(row, seg) = element offset of that row within segment ``seg``
+// (or -1 when the row is all zeros there); step(row, d) moves to row r + d.
 struct PlainRows {
     long ld;
-    long seg_stride;
-    __device__ __forceinline__ long off(int r, int seg) const { return (long)r * ld + (long)seg * seg_stride; }
+    struct Row { long base; };
+    __device__ __forceinline__ Row prep(int r) const { return Row{(long)r * ld}; }
+    __device__ __forceinline__ long off(const Row& x, int) const { return x.base; }
+    __device__ __forceinline__ void step(Row& x, int d) const { x.base += (long)d * ld; }
 };
 
 // Rows of the im2col matrix of a 3x3 / stride-2 / "same" convolution over an NHWC tensor
@@ -74,33 +126,53 @@ struct PlainRows {
 // input pixel (2*ho - pad_h + kh, 2*wo - pad_w + kw), zero outside the image.
 struct ConvFwdRows {
     int H, W, C, Ho, Wo, pad_h, pad_w;
-    __device__ __forceinline__ long off(int r, int seg) const {
-        int wo = r % Wo;
+    struct Row { int b, ho, wo; };
+    __device__ __forceinline__ Row prep(int r) const {
+        Row x;
+        x.wo = r % Wo;
         int t = r / Wo;
-        int ho = t % Ho;
-        int b = t / Ho;
-        int kh = seg / 3, kw = seg - kh * 3;
-        int h = 2 * ho - pad_h + kh, w = 2 * wo - pad_w + kw;
+        x.ho = t % Ho;
+        x.b = t / Ho;
+        return x;
+    }
+    __device__ __forceinline__ long off(const Row& x, int seg) const {
+        const int kh = seg / 3, kw = seg - kh * 3;
+        const int h = 2 * x.ho - pad_h + kh, w = 2 * x.wo - pad_w + kw;
         if (h < 0 || h >= H || w < 0 || w >= W) return -1;
-        return (((long)b * H + h) * W + w) * C;
+        return (((long)x.b * H + h) * W + w) * C;
+    }
+    __device__ __forceinline__ void step(Row& x, int d) const {
+        x.wo += d;
+        while (x.wo >= Wo) { x.wo -= Wo; ++x.ho; }
+        while (x.ho >= Ho) { x.ho -= Ho; ++x.b; }
     }
 };
 
 // Rows for the input gradient of the same convolution, one launch per parity class of the
-// input pixel.  Row r = (b, ah, aw) <-> input pixel (2*ah + ph - pad_h, 2*aw + pw - pad_w)
-// where (ph, pw) is the class; segment s indexes the taps that reach this class; the row is
-// the Cout-vector of the output gradient at (ah + dh[s], aw + dw[s]).
+// input pixel.  Row r = (b, ah, aw) <-> one input pixel of the class; segment s indexes the taps
+// that reach this class; the row is the Cout-vector of the output gradient at
+// (ah + dh[s], aw + dw[s]).
 struct ConvDgradRows {
     int Ho, Wo, Co, Ah, Aw;     // Ah x Aw = pixels of this class per image
     int dh[4], dw[4];
-    __device__ __forceinline__ long off(int r, int seg) const {
-        int aw = r % Aw;
+    struct Row { int b, ah, aw; };
+    __device__ __forceinline__ Row prep(int r) const {
+        Row x;
+        x.aw = r % Aw;
         int t = r / Aw;
-        int ah = t % Ah;
-        int b = t / Ah;
-        int ho = ah + dh[seg], wo = aw + dw[seg];
+        x.ah = t % Ah;
+        x.b = t / Ah;
+        return x;
+    }
+    __device__ __forceinline__ long off(const Row& x, int seg) const {
+        const int ho = x.ah + dh[seg], wo = x.aw + dw[seg];
         if (ho < 0 || ho >= Ho || wo < 0 || wo >= Wo) return -1;
-        return (((long)b * Ho + ho) * Wo + wo) * Co;
+        return (((long)x.b * Ho + ho) * Wo + wo) * Co;
+    }
+    __device__ __forceinline__ void step(Row& x, int d) const {
+        x.aw += d;
+        while (x.aw >= Aw) { x.aw -= Aw; ++x.ah; }
+        while (x.ah >= Ah) { x.ah -= Ah; ++x.b; }
     }
 };
 
@@ -115,9 +187,9 @@ struct GemmProblem {
     long ldb;                // leading dimension of B
     long b_seg_off[9];       // element offset of B for each segment
     int seg_base;            // segment index passed to the row map = seg_base + local segment
-    int split_k;             // number of K splits (grid.z); splits are over k-tiles
-    // when TA: the output rows m index the contiguous dimension of A and the contraction index
-    // runs over A's (mapped) rows; ``rows_a`` = number of contraction rows per segment.
+    int split_k;             // number of K splits; splits are over k-tiles
+    int zbatch;              // independent problems in grid.z (grid.z = zbatch * split_k); batch z uses
+    long c_batch_stride;     //   row-map segment seg_base + z and output C + z * c_batch_stride (fp32 elements)
     Epilogue epi;
     // optional output row remap for strided scatter of C rows (ConvDgrad): row m -> c_row(m)
     int crow_mode;           // 0: identity; 1: parity-class scatter
@@ -135,22 +207,68 @@ __device__ __forceinline__ int out_row(const GemmProblem<AMap>& p, int m) {
 }
 
 // ------------------------------------------------------------------ MFMA core (bf16)
-#define GM_BK 32
-#define GM_LDS_STRIDE 40   // bf16 elements per LDS row: 32 + 8 pad (80 B, 16-B aligned)
+#define GM_BK 64
 
 // Workgroup = 4 waves as 2 (M) x 2 (N); each wave owns WT x WT MFMA tiles of 16x16, so the
 // workgroup tile is (32*WT) x (32*WT): WT = 4 -> 128x128 (large outputs), WT = 2 -> 64x64
-// (small outputs, more workgroups in flight).
-// TA = false: A(m, k) = A[amap.off(m, seg) + kk]                (contraction contiguous)
-// TA = true : A(m, k) = A[amap.off(kk_row, seg) + m]            (output row contiguous)
-// TB = true : B(k, n) = B[b_seg_off[seg] + n*ldb + kk]          (contraction contiguous, "[N][K]")
-// TB = false: B(k, n) = B[b_seg_off[seg] + kk*ldb + n]          ("[K][N]")
+// (small outputs, more workgroups in flight).  K advances 64 per LDS stage, two stages.
+//
+// Operand layouts and their LDS images:
+//   TA = false: A(m, k) = A[row(m) + k]   contraction contiguous -> image [m][k], row read (ds_read_b128)
+//   TA = true : A(m, k) = A[row(k) + m]   output row contiguous  -> image [k][m], transposed read
+//   TB = true : B(k, n) = B[seg_off + n*ldb + k]   -> image [n][k], row read
+//   TB = false: B(k, n) = B[seg_off + k*ldb + n]   -> image [k][n], transposed read
+// A transposed read is two ds_read_b64_tr_b16 per fragment: each hands a lane the four k-values
+// of its column from a 4 x 16 block of 16-bit elements.
+//
+// The MFMA is issued with the operands swapped (B-fragment first), so a lane ends up with four
+// CONSECUTIVE columns of one output row: D[n = 4*(lane>>4) + r][m = lane & 15].  The epilogue
+// then stores 8 or 16 contiguous bytes per lane.
+// LDS images are unpadded and XOR-swizzled at 16-byte (8-element) chunk granularity.
+//   row-major image [rows][64 k]: chunk c of row r lives in slot c ^ (r & 7); the 16 lanes of a
+//     ds_read_b128 group then touch 16 different 16-byte slots of the 256-byte bank row.
+//   transposed image [64 k][NC*8 columns]: chunk c of k-row k lives in slot c ^ tr_swz<NC>(k), so the
+//     eight k-rows a 32-lane half of ds_read_b64_tr_b16 touches land on different banks.
+__device__ __forceinline__ int row_img_off(int r, int chunk) { return (r * 8 + (chunk ^ (r & 7))) * 8; }
+template <int NC>
+__device__ __forceinline__ int tr_swz(int k) {
+    return NC >= 16 ? (2 * (k & 3) + 8 * ((k >> 3) & 1)) : (2 * ((k >> 1) & 1) + 4 * ((k >> 3) & 1));
+}
+template <int NC>
+__device__ __forceinline__ int tr_img_off(int k, int chunk) { return (k * NC + (chunk ^ tr_swz<NC>(k))) * 8; }
+
+__device__ __forceinline__ bf16x8_t lds_frag_rows(const bf16_t* img, int row, int kofs) {
+    return *(const bf16x8_t*)(img + row_img_off(row, kofs >> 3));
+}
+template <int NC>
+__device__ __forceinline__ bf16x8_t lds_frag_tr(const bf16_t* img, int col0, int k0, int lane) {
+    // block rows k0 + 8g + q (q = 0..3), then + 4; lane 4q+p of the 16-lane group addresses row q, columns 4p..4p+3
+    const int g = lane >> 4, ig = lane & 15, q = ig >> 2, pp = ig & 3;
+    const int k = k0 + 8 * g + q;
+    const int chunk = (col0 >> 3) + (pp >> 1);
+    const bf16_t* a0 = img + tr_img_off<NC>(k, chunk) + (pp & 1) * 4;
+    const bf16_t* a1 = img + tr_img_off<NC>(k + 4, chunk) + (pp & 1) * 4;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)a0);
+    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)a1);
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
 template <class AMap, bool TA, bool TB, int WT>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
-    constexpr int BT = 32 * WT;              // tile edge
-    constexpr int NCH = BT * 4 / 256;        // 16-byte pieces per thread per operand tile
-    __shared__ __attribute__((aligned(16))) bf16_t sA[BT * GM_LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[BT * GM_LDS_STRIDE];
+    // independent problems stacked in grid.z (the kernel argument itself is never written:
+    // a modified by-value struct would be spilled to scratch memory)
+    const int zb = p.zbatch > 1 ? (int)(blockIdx.z / p.split_k) : 0;
+    const int zsplit = p.zbatch > 1 ? (int)(blockIdx.z % p.split_k) : (int)blockIdx.z;
+    const int seg_base = p.seg_base + zb;
+    const long coff = (long)zb * p.c_batch_stride;
+    constexpr int BT = 32 * WT;                       // tile edge
+    constexpr int NCH = BT * (GM_BK / 8) / 256;       // 16-byte pieces per thread per operand stage
+    constexpr int NC = BT / 8;                        // 16-byte chunks per row of a transposed image
+    constexpr int A_ELEMS = BT * GM_BK, B_ELEMS = BT * GM_BK;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_ELEMS + B_ELEMS)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -164,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
     const int tiles_per_seg = (p.kseg + GM_BK - 1) / GM_BK;
     const int ntiles = p.nseg * tiles_per_seg;
     const int per_split = (ntiles + p.split_k - 1) / p.split_k;
-    const int t_begin = blockIdx.z * per_split;
+    const int t_begin = zsplit * per_split;
     const int t_end = min(ntiles, t_begin + per_split);
 
     f32x4_t acc[WT][WT];
@@ -172,6 +290,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
     for (int i = 0; i < WT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // per-thread staging pieces.  Row-major operand: piece c -> (row c/8, k-chunk c%8);
+    // transposed operand: piece c -> (k-row c/(BT/8), column chunk c%(BT/8)).
+    typename AMap::Row arow[NCH];
+    bool avalid[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + 256 * i;
+        if (!TA) {
+            const int m = bm + (c >> 3);
+            avalid[i] = m < p.M;
+            arow[i] = p.amap.prep(avalid[i] ? m : 0);
+        } else {
+            // rows follow the contraction index: start at the first tile of this split (nseg == 1)
+            const int k = t_begin * GM_BK + c / (BT / 8);
+            avalid[i] = true;
+            arow[i] = p.amap.prep(k < p.kseg ? k : 0);
+        }
+    }
 
     uint4 ra[NCH], rb[NCH];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -183,131 +320,198 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 256 * i;
             if (!TA) {
-                const int row = c >> 2, kc = (c & 3) * 8;
-                const int m = bm + row, k = k0 + kc;
+                const int k = k0 + (c & 7) * 8;
                 uint4 v = zero4;
-                if (m < p.M && k < p.kseg) {
-                    long o = p.amap.off(m, p.seg_base + seg);
+                if (avalid[i] && k < p.kseg) {
+                    const long o = p.amap.off(arow[i], seg_base + seg);
                     if (o >= 0) v = *(const uint4*)(A + o + k);
                 }
                 ra[i] = v;
             } else {
-                const int kk = c / (BT / 8), mc = (c % (BT / 8)) * 8;
-                const int m = bm + mc, k = k0 + kk;
+                const int k = k0 + c / (BT / 8), m = bm + (c % (BT / 8)) * 8;
                 uint4 v = zero4;
                 if (m < p.M && k < p.kseg) {
-                    long o = p.amap.off(k, p.seg_base + seg);
+                    const long o = p.amap.off(arow[i], seg_base + seg);
                     if (o >= 0) v = *(const uint4*)(A + o + m);
                 }
                 ra[i] = v;
             }
             if (TB) {
-                const int row = c >> 2, kc = (c & 3) * 8;
-                const int n = bn + row, k = k0 + kc;
+                const int n = bn + (c >> 3), k = k0 + (c & 7) * 8;
                 uint4 v = zero4;
                 if (n < p.N && k < p.kseg) v = *(const uint4*)(B + p.b_seg_off[seg] + (long)n * p.ldb + k);
                 rb[i] = v;
             } else {
-                const int kk = c / (BT / 8), nc = (c % (BT / 8)) * 8;
-                const int n = bn + nc, k = k0 + kk;
+                const int k = k0 + c / (BT / 8), n = bn + (c % (BT / 8)) * 8;
                 uint4 v = zero4;
                 if (n < p.N && k < p.kseg) v = *(const uint4*)(B + p.b_seg_off[seg] + (long)k * p.ldb + n);
                 rb[i] = v;
             }
         }
+        if (TA) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) p.amap.step(arow[i], GM_BK);
+        }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        bf16_t* sA = lds + buf * (A_ELEMS + B_ELEMS);
+        bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = tid + 256 * i;
-            if (!TA) {
-                const int row = c >> 2, kc = (c & 3) * 8;
-                *(uint4*)(sA + row * GM_LDS_STRIDE + kc) = ra[i];
-            } else {
-                const int kk = c / (BT / 8), mc = (c % (BT / 8)) * 8;
-                const bf16_t* e = (const bf16_t*)&ra[i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sA[(mc + j) * GM_LDS_STRIDE + kk] = e[j];
-            }
-            if (TB) {
-                const int row = c >> 2, kc = (c & 3) * 8;
-                *(uint4*)(sB + row * GM_LDS_STRIDE + kc) = rb[i];
-            } else {
-                const int kk = c / (BT / 8), nc = (c % (BT / 8)) * 8;
-                const bf16_t* e = (const bf16_t*)&rb[i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sB[(nc + j) * GM_LDS_STRIDE + kk] = e[j];
-            }
+            if (!TA) *(uint4*)(sA + row_img_off(c >> 3, c & 7)) = ra[i];
+            else *(uint4*)(sA + tr_img_off<NC>(c / NC, c % NC)) = ra[i];
+            if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = rb[i];
+            else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = rb[i];
         }
     };
 
     if (t_begin < t_end) {
         load_tile(t_begin);
-        store_tile();
+        store_tile(0);
         __syncthreads();
+        int cur = 0;
         for (int t = t_begin; t < t_end; ++t) {
             const bool more = (t + 1 < t_end);
             if (more) load_tile(t + 1);
-            bf16x8_t af[WT], bfr[WT];
+            const bf16_t* sA = lds + cur * (A_ELEMS + B_ELEMS);
+            const bf16_t* sB = sA + A_ELEMS;
             const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
-                af[i] = *(const bf16x8_t*)(sA + (wm * 16 * WT + i * 16 + fr) * GM_LDS_STRIDE + fk);
+            for (int ks = 0; ks < GM_BK; ks += 32) {
+                bf16x8_t af[WT], bfr[WT];
 #pragma unroll
-            for (int j = 0; j < WT; ++j)
-                bfr[j] = *(const bf16x8_t*)(sB + (wn * 16 * WT + j * 16 + fr) * GM_LDS_STRIDE + fk);
+                for (int i = 0; i < WT; ++i) {
+                    const int m0 = wm * 16 * WT + i * 16;
+                    af[i] = TA ? lds_frag_tr<NC>(sA, m0, ks, lane) : lds_frag_rows(sA, m0 + fr, ks + fk);
+                }
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
+                for (int j = 0; j < WT; ++j) {
+                    const int n0 = wn * 16 * WT + j * 16;
+                    bfr[j] = TB ? lds_frag_rows(sB, n0 + fr, ks + fk) : lds_frag_tr<NC>(sB, n0, ks, lane);
+                }
 #pragma unroll
-                for (int j = 0; j < WT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            __syncthreads();
-            if (more) {
-                store_tile();
-                __syncthreads();
+                for (int i = 0; i < WT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
         }
     }
 
-    // epilogue: accumulator element r of tile (i, j) is C[row = (lane>>4)*4 + r][col = lane&15]
-    uint64_t key = 0;
-    if (p.epi.drop_thresh) key = rng_key(p.epi.rng_state, p.epi.rng_site);
+    // epilogue.  Element r of acc[i][j] is C[m = m0 + (lane & 15)][n = n0 + 4*(lane >> 4) + r].  The
+    // tile is first parked in LDS (fp32, 16-byte chunks XOR-swizzled by row), then every thread
+    // walks whole 8-column pieces of rows: bias/aux are read and C is written with 16-byte
+    // accesses along rows, and the code stays one small loop instead of WT*WT unrolled copies.
+    float* sC = (float*)lds;                      // BT*BT floats fit exactly in the two stages
     const int fq = lane >> 4, fr = lane & 15;
-    float csum[WT], csq[WT];
-#pragma unroll
-    for (int j = 0; j < WT; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < WT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = bm + wm * 16 * WT + i * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
-            const int mo = out_row(p, m);
+        for (int j = 0; j < WT; ++j) {
+            const int row = wm * 16 * WT + i * 16 + fr;
+            const int chunk = (wn * 16 * WT + j * 16) / 4 + fq;
+            *(f32x4_t*)(sC + row * BT + ((chunk ^ (row & 7)) * 4)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    uint64_t key = 0;
+    if (p.epi.drop_thresh) key = rng_key(p.epi.rng_state, p.epi.rng_site);
+    constexpr int CPR = BT / 8;                   // 8-column pieces per tile row
+    const bool vec8 = (p.epi.ldc % 8 == 0) && ((((uintptr_t)p.epi.C) & 15) == 0) &&
+                      (!p.epi.C_pre || (((uintptr_t)p.epi.C_pre) & 15) == 0);
+    float csum[8], csq[8];
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int n = bn + wn * 16 * WT + j * 16 + fr;
-                if (n < p.N) {
-                    epilogue_store(p.epi, mo, n, acc[i][j][r], key);
-                    if (p.epi.colsum) {
-                        float v = acc[i][j][r] * p.epi.alpha;
-                        if (p.epi.c_dtype == ATHENA_BF16) v = (float)(bf16_t)v;
-                        csum[j] += v;
-                        csq[j] += v * v;
-                    }
+    for (int r = 0; r < 8; ++r) { csum[r] = 0.f; csq[r] = 0.f; }
+    for (int idx = tid; idx < BT * CPR; idx += 256) {
+        const int row = idx / CPR, c8 = idx % CPR;     // 256 % CPR == 0: a thread keeps its columns
+        const int m = bm + row, n = bn + c8 * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const f32x4_t x0 = *(const f32x4_t*)(sC + row * BT + (((2 * c8) ^ (row & 7)) * 4));
+        const f32x4_t x1 = *(const f32x4_t*)(sC + row * BT + (((2 * c8 + 1) ^ (row & 7)) * 4));
+        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        const int mo = out_row(p, m);
+        const int nv = min(8, p.N - n);
+        const long ci = (long)mo * p.epi.ldc + n;
+        if (p.epi.atomic) {
+            float* c = (float*)p.epi.C + coff + ci;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r < nv) atomicAdd(c + r, v[r] * p.epi.alpha);
+            continue;
+        }
+        const long ai = (long)mo * p.epi.ldaux + n;
+        float pre[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            v[r] = (r < nv) ? epilogue_value(p.epi, ci + r, ai + r, n + r, v[r], key, &pre[r]) : 0.f;
+        if (p.epi.colsum) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float sv = v[r];
+                if (p.epi.c_dtype == ATHENA_BF16) sv = (float)(bf16_t)sv;
+                if (r < nv) { csum[r] += sv; csq[r] += sv * sv; }
+            }
+        }
+        if (nv == 8 && vec8) {
+            if (p.epi.c_dtype == ATHENA_BF16) {
+                bf16_t* c = (bf16_t*)p.epi.C + ci;
+                if (p.epi.C_pre) {
+                    bf16x8_t pv;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pv[r] = (bf16_t)pre[r];
+                    *(bf16x8_t*)((bf16_t*)p.epi.C_pre + ci) = pv;
+                }
+                if (p.epi.accum) {
+                    const bf16x8_t old = *(const bf16x8_t*)c;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)old[r];
+                }
+                bf16x8_t o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+                *(bf16x8_t*)c = o;
+            } else {
+                float* c = (float*)p.epi.C + ci;
+                if (p.epi.C_pre) {
+                    float* cp = (float*)p.epi.C_pre + ci;
+                    *(float4*)cp = make_float4(pre[0], pre[1], pre[2], pre[3]);
+                    *(float4*)(cp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+                }
+                if (p.epi.accum) {
+                    const float4 o0 = *(const float4*)c, o1 = *(const float4*)(c + 4);
+                    v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
+                    v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                }
+                *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r < nv) {
+                    if (p.epi.C_pre) store_from_f32(p.epi.C_pre, ci + r, p.epi.c_dtype, pre[r]);
+                    float o = v[r];
+                    if (p.epi.accum) o += load_as_f32(p.epi.C, ci + r, p.epi.c_dtype);
+                    store_from_f32(p.epi.C, ci + r, p.epi.c_dtype, o);
                 }
             }
         }
     }
     if (p.epi.colsum) {
-        // lanes with equal (lane & 15) hold the same column: fold the 4 row groups, then one atomic per column
+        // threads with equal (tid % CPR) own the same 8 columns: fold inside the wave, then one
+        // fp64 atomic per column per wave
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
-            float s = csum[j], q = csq[j];
-            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-            const int n = bn + wn * 16 * WT + j * 16 + fr;
-            if (fq == 0 && n < p.N) {
-                atomicAdd(p.epi.colsum + n, (double)s);
+        for (int r = 0; r < 8; ++r) {
+            float sm = csum[r], q = csq[r];
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
+            const int n = bn + (tid % CPR) * 8 + r;
+            if ((lane / CPR) == 0 && n < p.N) {
+                atomicAdd(p.epi.colsum + n, (double)sm);
                 atomicAdd(p.epi.colsum + p.N + n, (double)q);
             }
         }
@@ -321,6 +525,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
 
 template <class AMap, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
+    const int zb = p.zbatch > 1 ? (int)(blockIdx.z / p.split_k) : 0;
+    const int zsplit = p.zbatch > 1 ? (int)(blockIdx.z % p.split_k) : (int)blockIdx.z;
+    const int seg_base = p.seg_base + zb;
+    const long coff = (long)zb * p.c_batch_stride;
     __shared__ float sA[GV_BK][GV_BM + 4];
     __shared__ float sB[GV_BK][GV_BN + 4];
     const int tid = threadIdx.x;
@@ -332,7 +540,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
     const int tiles_per_seg = (p.kseg + GV_BK - 1) / GV_BK;
     const int ntiles = p.nseg * tiles_per_seg;
     const int per_split = (ntiles + p.split_k - 1) / p.split_k;
-    const int t_begin = blockIdx.z * per_split;
+    const int t_begin = zsplit * per_split;
     const int t_end = min(ntiles, t_begin + per_split);
 
     float acc[4][4];
@@ -355,10 +563,10 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
                 float v = 0.f;
                 if (m < p.M && k < p.kseg) {
                     if (!TA) {
-                        long o = p.amap.off(m, p.seg_base + seg);
+                        long o = p.amap.off(p.amap.prep(m), seg_base + seg);
                         if (o >= 0) v = A[o + k];
                     } else {
-                        long o = p.amap.off(k, p.seg_base + seg);
+                        long o = p.amap.off(p.amap.prep(k), seg_base + seg);
                         if (o >= 0) v = A[o + m];
                     }
                 }
@@ -402,7 +610,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
         for (int j = 0; j < 4; ++j) {
             const int n = bn + tx * 4 + j;
             if (n < p.N) {
-                epilogue_store(p.epi, mo, n, acc[i][j], key);
+                epilogue_store(p.epi, mo, n, acc[i][j], key, coff);
                 if (p.epi.colsum) {
                     float v = acc[i][j] * p.epi.alpha;
                     atomicAdd(p.epi.colsum + n, (double)v);
@@ -413,13 +621,13 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
     }
 }
 
-// number of workgroups a launch would use with the large (128) / small (64) tile
+// number of workgroups a launch would use with tile edge ``bt``
 static inline long gemm_tiles(int M, int N, int bt) { return (long)((M + bt - 1) / bt) * ((N + bt - 1) / bt); }
 
 template <class AMap, int WT>
 static void launch_mfma(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_t stream) {
     constexpr int BT = 32 * WT;
-    dim3 grid((p.M + BT - 1) / BT, (p.N + BT - 1) / BT, p.split_k);
+    dim3 grid((p.M + BT - 1) / BT, (p.N + BT - 1) / BT, p.split_k * (p.zbatch > 1 ? p.zbatch : 1));
     if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, true, WT>), grid, dim3(256), 0, stream, p);
     else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, false, WT>), grid, dim3(256), 0, stream, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, false, WT>), grid, dim3(256), 0, stream, p);
@@ -435,7 +643,7 @@ static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool t
         if (gemm_mfma_tile(p.M, p.N) == 128) launch_mfma<AMap, 4>(p, ta, tb, stream);
         else launch_mfma<AMap, 2>(p, ta, tb, stream);
     } else {
-        dim3 grid((p.M + GV_BM - 1) / GV_BM, (p.N + GV_BN - 1) / GV_BN, p.split_k);
+        dim3 grid((p.M + GV_BM - 1) / GV_BM, (p.N + GV_BN - 1) / GV_BN, p.split_k * (p.zbatch > 1 ? p.zbatch : 1));
         if (!ta && tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, false, true>), grid, dim3(256), 0, stream, p);
         else if (!ta && !tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, false, false>), grid, dim3(256), 0, stream, p);
         else if (ta && !tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, true, false>), grid, dim3(256), 0, stream, p);
@@ -445,8 +653,8 @@ static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool t
     return ATHENA_OK;
 }
 
-// split-K factor for an output of M x N with ``ktiles`` contraction tiles: enough workgroups to
-// fill the chip (~512) without multiplying the atomic traffic more than needed
+// split-K factor for an output of M x N with ``k_elems`` contraction elements: enough
+// workgroups to fill the chip (~512) without multiplying the atomic traffic more than needed
 static inline int gemm_auto_split(int M, int N, long k_elems, int in_dtype) {
     const int bt = in_dtype == ATHENA_BF16 ? gemm_mfma_tile(M, N) : GV_BM;
     const int bk = in_dtype == ATHENA_BF16 ? GM_BK : GV_BK;
