@@ -26,6 +26,7 @@ class GemmDesc(Structure):
         ("in_dtype", c_int32), ("out_dtype", c_int32), ("aux_dtype", c_int32),
         ("act", c_int32), ("accumulate", c_int32), ("split_k", c_int32),
         ("alpha", c_float), ("drop_p", c_float), ("rng_site", c_uint32),
+        ("b_colsum", c_void_p), ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -44,6 +45,7 @@ _SIGNATURES = {
     "athena_last_error": (c_char_p, []),
     "athena_abi_version": (c_int, []),
     "athena_gemm": (c_int, [POINTER(GemmDesc), _S]),
+    "athena_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "athena_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,
                                          _P, _P, _P, _P, _S]),
@@ -55,7 +57,8 @@ _SIGNATURES = {
                                c_int, c_float, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _S]),
     "athena_conv3x3s2_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_conv3x3s2_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _S]),
-    "athena_conv3x3s2_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _S]),
+    "athena_conv3x3s2_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
+    "athena_conv3x3s2_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "athena_conv3x3s2_small_cin_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_conv3x3s2_small_cin_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _S]),
     "athena_bn_finalize": (c_int, [_P, c_long, c_int, c_float, c_float, _P, _P, _P, _S]),

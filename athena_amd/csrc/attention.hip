@@ -1,4 +1,5 @@
-// Fused multi-head attention, forward and backward, vector-ALU version.
+// Fused multi-head attention, forward and backward: entry points, and the vector-ALU kernels
+// used for fp32 operands and for head sizes the matrix-core kernels (attention_mfma.h) do not take.
 //
 // One thread group of P lanes owns one query row (forward, dQ pass) or one key row (dK/dV pass)
 // and keeps its DK/P-wide slices of the row vectors in registers; the rows of the other side
@@ -6,6 +7,8 @@
 // The additive mask is the reference's fp32 arithmetic, s + (-1e9), so fully masked rows
 // come out as the same uniform average.
 #include "common.h"
+#include "attention_mfma.h"
+#include <initializer_list>
 
 #define ATT_TILE 32        // rows of the streamed side per LDS tile
 #define ATT_BLOCK 128      // threads per block
@@ -266,6 +269,23 @@ static int mha_check(const char* name, int B, int h, int Tq, int Tk, int dk, int
     return ATHENA_OK;
 }
 
+// the matrix-core kernels take bf16, head sizes 32/64/128 and 16-byte aligned rows
+static bool mha_mfma_ok(int dtype, int dk, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (dtype != ATHENA_BF16 || !(dk == 32 || dk == 64 || dk == 128)) return false;
+    for (int ld : lds)
+        if (ld % 8) return false;
+    for (const void* p : ptrs)
+        if (!athena_aligned16(p)) return false;
+    return true;
+}
+
+#define MHA_MFMA_DISPATCH(KERNEL, GRID, ...)                                                     \
+    do {                                                                                         \
+        if (dk == 32) hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(256), 0, s, __VA_ARGS__);      \
+        else if (dk == 64) hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<128>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+    } while (0)
+
 #define MHA_DISPATCH(KERNEL, T, ...)                                                                          \
     do {                                                                                                      \
         switch (dk) {                                                                                         \
@@ -291,6 +311,14 @@ extern "C" int athena_mha_fwd(const void* q, const void* k, const void* v, int l
     ATHENA_REQUIRE(ldq >= h * dk && ldk >= h * dk && ldv >= h * dk && ldo >= h * dk, ATHENA_E_SHAPE, "athena_mha_fwd: leading dimension too small");
     hipStream_t s = (hipStream_t)stream;
     const int rows = Tq;
+    if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo}, {q, k, v, out})) {
+        ATHENA_REQUIRE((long)B * h <= 65535, ATHENA_E_SHAPE, "athena_mha_fwd: B*h too large");
+        const dim3 grid((Tq + AM_ROWS - 1) / AM_ROWS, B * h);
+        MHA_MFMA_DISPATCH(mha_fwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                          key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse);
+        ATHENA_CHECK_LAUNCH("athena_mha_fwd");
+        return ATHENA_OK;
+    }
     if (dtype == ATHENA_BF16)
         MHA_DISPATCH(mha_fwd_kernel, bf16_t, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse);
     else
@@ -311,6 +339,18 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * h * Tq;
     dim3 gd((unsigned)((total + 255) / 256));
+    if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo, lddq, lddk, lddv}, {q, k, v, out, dout, dq, dk_, dv})) {
+        ATHENA_REQUIRE((long)B * h <= 65535, ATHENA_E_SHAPE, "athena_mha_bwd: B*h too large");
+        MHA_MFMA_DISPATCH(mha_delta_mfma_kernel, gd, (const bf16_t*)out, (const bf16_t*)dout, ldo, h, Tq, total, delta);
+        const dim3 gq((Tq + AM_ROWS - 1) / AM_ROWS, B * h), gk((Tk + AM_ROWS - 1) / AM_ROWS, B * h);
+        MHA_MFMA_DISPATCH(mha_bwd_dq_mfma_kernel, gq, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dq, lddq);
+        MHA_MFMA_DISPATCH(mha_bwd_dkv_mfma_kernel, gk, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dk_,
+                          (bf16_t*)dv, lddk, lddv);
+        ATHENA_CHECK_LAUNCH("athena_mha_bwd");
+        return ATHENA_OK;
+    }
     if (dtype == ATHENA_BF16)
         hipLaunchKernelGGL(mha_delta_kernel<bf16_t>, gd, dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, ldo, h, Tq, dk, total, delta);
     else

@@ -1,0 +1,473 @@
+// Fused multi-head attention on the matrix cores (bf16 operands, fp32 softmax and accumulation).
+//
+// Workgroup = 4 waves; a wave owns 16 rows of the "resident" side (queries in the forward and
+// dQ kernels, keys in the dK/dV kernel) and walks the other side in blocks of 64 rows that are
+// staged through a double-buffered LDS image.  Every product is issued so that the 16 resident
+// rows are the COLUMNS of the MFMA result: a lane then holds, for resident row (lane & 15), four
+// consecutive rows 4*(lane >> 4) + r of each 16-row tile of the streamed side.  With that layout
+//   * the softmax statistics of a query live in the lane(s) that also hold its output columns,
+//   * the probabilities a lane holds are exactly the B-operand fragment of the next product
+//     (the contraction index is a permutation of the streamed rows, applied identically to the
+//     A operand through the transposing LDS read), so P and dS never travel through LDS.
+// Scores never leave the chip.  The additive mask is the reference's fp32 arithmetic,
+// s * scale + (-1e9), so fully masked rows come out as the same uniform average
+// (athena/layers/attention.py:47-70).
+#pragma once
+#include "common.h"
+
+#define AM_ROWS 64      // rows per workgroup on the resident side and per LDS block on the streamed side
+
+template <int DK>
+struct AttImg {
+    static constexpr int NC = DK / 8;     // 16-byte chunks per row
+    // chunk swizzle: conflict-free for 8 consecutive rows reading one chunk (ds_read_b128) and for
+    // 4 consecutive rows reading a pair of chunks (ds_read_b64_tr_b16)
+    __device__ static __forceinline__ int swz(int r) {
+        return DK == 32 ? ((((r >> 1) & 1) << 1) | ((r >> 2) & 1)) : (((r & 3) << 1) | ((r >> 2) & 1));
+    }
+    __device__ static __forceinline__ int off(int r, int chunk) { return (r * NC + (chunk ^ swz(r))) * 8; }
+};
+
+// register-staged copy of a [64][DK] block of rows (row stride ld) into an LDS image
+template <int DK>
+struct AttStage {
+    static constexpr int NC = DK / 8;
+    static constexpr int NP = AM_ROWS * NC / 256;
+    uint4 r[NP];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int c = tid + 256 * i;
+            const int row = row0 + c / NC, ch = c % NC;
+            const int rc = row < nrows ? row : nrows - 1;
+            uint4 v = *(const uint4*)(base + (long)rc * ld + ch * 8);
+            if (row >= nrows) v = make_uint4(0, 0, 0, 0);
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int c = tid + 256 * i;
+            *(uint4*)(img + AttImg<DK>::off(c / NC, c % NC)) = r[i];
+        }
+    }
+};
+
+// A-operand fragment from image rows: row (row0 + lane & 15), elements 32*ks + 8*(lane >> 4) .. +7
+template <int DK>
+__device__ __forceinline__ bf16x8_t att_frag_rows(const bf16_t* img, int row0, int ks, int lane) {
+    return *(const bf16x8_t*)(img + AttImg<DK>::off(row0 + (lane & 15), 4 * ks + (lane >> 4)));
+}
+
+// A-operand fragment of the TRANSPOSED image: for output row (col0 + lane & 15) the eight
+// contraction slots of lane group g = lane >> 4 are image rows ra + 4g + {0..3}, rb + 4g + {0..3}
+template <int DK>
+__device__ __forceinline__ bf16x8_t att_frag_tr(const bf16_t* img, int ra, int rb, int col0, int lane) {
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const int g = lane >> 4, ig = lane & 15, q = ig >> 2, pp = ig & 3;
+    const int chunk = (col0 >> 3) + (pp >> 1);
+    const bf16_t* a0 = img + AttImg<DK>::off(ra + 4 * g + q, chunk) + (pp & 1) * 4;
+    const bf16_t* a1 = img + AttImg<DK>::off(rb + 4 * g + q, chunk) + (pp & 1) * 4;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)a0);
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)a1);
+    const s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t att_pack(const f32x4_t a, const f32x4_t b) {
+    bf16x8_t o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)a[r]; o[4 + r] = (bf16_t)b[r]; }
+    return o;
+}
+
+// eight elements of row min(row, nrows - 1) of a matrix, zeroed when row >= nrows (the load itself is
+// always in bounds, so the select is on the data and nothing goes through scratch memory)
+__device__ __forceinline__ bf16x8_t att_load8(const bf16_t* base, int row, int nrows, int ld, int col) {
+    const int rc = row < nrows ? row : nrows - 1;
+    uint4 v = *(const uint4*)(base + (long)rc * ld + col);
+    if (row >= nrows) v = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// flags of the 64 streamed keys of a block: 0 = attend, 1 = masked (-1e9), 2 = past the end
+__device__ __forceinline__ uint8_t att_key_flag(const uint8_t* __restrict__ key_mask, long b, int Tk, int kj) {
+    if (kj >= Tk) return 2;
+    return (key_mask && key_mask[b * Tk + kj]) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- forward
+template <int DK>
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+                                                           const uint8_t* __restrict__ key_mask, int causal, int h,
+                                                           int Tq, int Tk, float scale, bf16_t* __restrict__ out,
+                                                           int ldo, float* __restrict__ lse) {
+    constexpr int KS = DK / 32, NT = DK / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) uint8_t sM[2][AM_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    const bf16_t* qb = q + (long)b * Tq * ldq + hh * DK;
+    const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
+    const bf16_t* vb = v + (long)b * Tk * ldv + hh * DK;
+    const int qi = blockIdx.x * AM_ROWS + wave * 16 + li;
+
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = att_load8(qb, qi, Tq, ldq, 32 * ks + 8 * g);
+    f32x4_t o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lp = 0.f;
+
+    AttStage<DK> stK, stV;
+    uint8_t mflag = 0;
+    const int nblk = (Tk + AM_ROWS - 1) / AM_ROWS;
+    stK.load(kb, ldk, 0, Tk, tid);
+    stV.load(vb, ldv, 0, Tk, tid);
+    if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, tid);
+    stK.store(sK[0], tid);
+    stV.store(sV[0], tid);
+    if (tid < AM_ROWS) sM[0][tid] = mflag;
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1, j0 = blk * AM_ROWS;
+        const bool more = blk + 1 < nblk;
+        if (more) {
+            stK.load(kb, ldk, j0 + AM_ROWS, Tk, tid);
+            stV.load(vb, ldv, j0 + AM_ROWS, Tk, tid);
+            if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, j0 + AM_ROWS + tid);
+        }
+        // scores, transposed: s[jt][r] = q(qi) . k(j0 + 16 jt + 4 g + r)
+        f32x4_t s[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sK[cur], 16 * jt, ks, lane), qf[ks],
+                                                                s[jt], 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const uint32_t mk = ((const uint32_t*)sM[cur])[4 * jt + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t f = (mk >> (8 * r)) & 0xffu;
+                const int kj = j0 + 16 * jt + 4 * g + r;
+                float sv = s[jt][r] * scale;
+                if (f == 1u || (causal && kj > qi)) sv += -1e9f;
+                if (f == 2u) sv = -INFINITY;
+                s[jt][r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __expf(m - mn);          // first block: exp(-inf) = 0
+        m = mn;
+        float psum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[jt][r] - mn);   // keys past the end: exp(-inf) = 0
+                s[jt][r] = p;
+                psum += p;
+            }
+        lp = lp * alpha + psum;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+        // out^T[d][query] += sum_key v[key][d] p[query][key]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8_t pf = att_pack(s[2 * kk], s[2 * kk + 1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    att_frag_tr<DK>(sV[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), pf, o[nt], 0, 0, 0);
+        }
+        if (more) {
+            stK.store(sK[cur ^ 1], tid);
+            stV.store(sV[cur ^ 1], tid);
+            if (tid < AM_ROWS) sM[cur ^ 1][tid] = mflag;
+        }
+        __syncthreads();
+    }
+    float l = lp;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qi < Tq) {
+        const float inv = 1.f / l;
+        bf16_t* ob = out + ((long)b * Tq + qi) * ldo + hh * DK + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4_t w = {(bf16_t)(o[nt][0] * inv), (bf16_t)(o[nt][1] * inv), (bf16_t)(o[nt][2] * inv),
+                          (bf16_t)(o[nt][3] * inv)};
+            *(bf16x4_t*)(ob + 16 * nt) = w;
+        }
+        if (g == 0) lse[((long)b * h + hh) * Tq + qi] = m + __logf(l);
+    }
+}
+
+// ---------------------------------------------------------------- backward
+// delta[b,h,i] = sum_c dout[b,i,h,c] * out[b,i,h,c]; one thread per (b, i, h)
+template <int DK>
+__global__ __launch_bounds__(256) void mha_delta_mfma_kernel(const bf16_t* __restrict__ out,
+                                                             const bf16_t* __restrict__ dout, int ldo, int h, int Tq,
+                                                             long total, float* __restrict__ delta) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // (b * Tq + i) * h + hh
+    if (idx >= total) return;
+    const int hh = (int)(idx % h);
+    const long bi = idx / h;
+    const int i = (int)(bi % Tq);
+    const long b = bi / Tq;
+    const long o = bi * ldo + hh * DK;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DK; c += 8) {
+        const bf16x8_t a = *(const bf16x8_t*)(out + o + c);
+        const bf16x8_t d = *(const bf16x8_t*)(dout + o + c);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += (float)a[r] * (float)d[r];
+    }
+    delta[(b * h + hh) * Tq + i] = s;
+}
+
+// dQ: a wave owns 16 queries, keys/values streamed
+template <int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                              const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+                                                              const uint8_t* __restrict__ key_mask, int causal, int h,
+                                                              int Tq, int Tk, float scale,
+                                                              const bf16_t* __restrict__ dout, int ldo,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta, bf16_t* __restrict__ dq,
+                                                              int lddq) {
+    constexpr int KS = DK / 32, NT = DK / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) uint8_t sM[2][AM_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
+    const bf16_t* vb = v + (long)b * Tk * ldv + hh * DK;
+    const int qi = blockIdx.x * AM_ROWS + wave * 16 + li;
+    const bool qok = qi < Tq;
+
+    bf16x8_t qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = att_load8(q + (long)b * Tq * ldq + hh * DK, qi, Tq, ldq, 32 * ks + 8 * g);
+        dof[ks] = att_load8(dout + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+    }
+    const float lse_i = qok ? lse[((long)b * h + hh) * Tq + qi] : INFINITY;
+    const float del_i = qok ? delta[((long)b * h + hh) * Tq + qi] : 0.f;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    AttStage<DK> stK, stV;
+    uint8_t mflag = 0;
+    const int nblk = (Tk + AM_ROWS - 1) / AM_ROWS;
+    stK.load(kb, ldk, 0, Tk, tid);
+    stV.load(vb, ldv, 0, Tk, tid);
+    if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, tid);
+    stK.store(sK[0], tid);
+    stV.store(sV[0], tid);
+    if (tid < AM_ROWS) sM[0][tid] = mflag;
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1, j0 = blk * AM_ROWS;
+        const bool more = blk + 1 < nblk;
+        if (more) {
+            stK.load(kb, ldk, j0 + AM_ROWS, Tk, tid);
+            stV.load(vb, ldv, j0 + AM_ROWS, Tk, tid);
+            if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, j0 + AM_ROWS + tid);
+        }
+        f32x4_t s[4], dp[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dp[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sK[cur], 16 * jt, ks, lane), qf[ks],
+                                                                s[jt], 0, 0, 0);
+                dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sV[cur], 16 * jt, ks, lane), dof[ks],
+                                                                 dp[jt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const uint32_t mk = ((const uint32_t*)sM[cur])[4 * jt + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t f = (mk >> (8 * r)) & 0xffu;
+                const int kj = j0 + 16 * jt + 4 * g + r;
+                float sv = s[jt][r] * scale;
+                if (f == 1u || (causal && kj > qi)) sv += -1e9f;
+                if (f == 2u) sv = -INFINITY;
+                const float p = __expf(sv - lse_i);
+                s[jt][r] = p * (dp[jt][r] - del_i) * scale;     // dS
+            }
+        }
+        // dq^T[d][query] += sum_key k[key][d] dS[query][key]
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8_t dsf = att_pack(s[2 * kk], s[2 * kk + 1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    att_frag_tr<DK>(sK[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), dsf, acc[nt], 0, 0, 0);
+        }
+        if (more) {
+            stK.store(sK[cur ^ 1], tid);
+            stV.store(sV[cur ^ 1], tid);
+            if (tid < AM_ROWS) sM[cur ^ 1][tid] = mflag;
+        }
+        __syncthreads();
+    }
+    if (qok) {
+        bf16_t* ob = dq + ((long)b * Tq + qi) * lddq + hh * DK + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4_t w = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
+            *(bf16x4_t*)(ob + 16 * nt) = w;
+        }
+    }
+}
+
+// dK, dV: a wave owns 16 keys, queries / dout streamed
+template <int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                               const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+                                                               const uint8_t* __restrict__ key_mask, int causal, int h,
+                                                               int Tq, int Tk, float scale,
+                                                               const bf16_t* __restrict__ dout, int ldo,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, bf16_t* __restrict__ dk_,
+                                                               bf16_t* __restrict__ dv, int lddk, int lddv) {
+    constexpr int KS = DK / 32, NT = DK / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t sO[2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) float sL[2][AM_ROWS];
+    __shared__ __attribute__((aligned(16))) float sD[2][AM_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    const bf16_t* qb = q + (long)b * Tq * ldq + hh * DK;
+    const bf16_t* ob = dout + (long)b * Tq * ldo + hh * DK;
+    const float* lb = lse + ((long)b * h + hh) * Tq;
+    const float* db = delta + ((long)b * h + hh) * Tq;
+    const int kj = blockIdx.x * AM_ROWS + wave * 16 + li;
+    const bool kok = kj < Tk;
+
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = att_load8(k + (long)b * Tk * ldk + hh * DK, kj, Tk, ldk, 32 * ks + 8 * g);
+        vf[ks] = att_load8(v + (long)b * Tk * ldv + hh * DK, kj, Tk, ldv, 32 * ks + 8 * g);
+    }
+    const bool kmask = kok && key_mask && key_mask[(long)b * Tk + kj];
+    f32x4_t ak[NT], av[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ak[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        av[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    AttStage<DK> stQ, stO;
+    float rl = 0.f, rd = 0.f;
+    const int nblk = (Tq + AM_ROWS - 1) / AM_ROWS;
+    stQ.load(qb, ldq, 0, Tq, tid);
+    stO.load(ob, ldo, 0, Tq, tid);
+    if (tid < AM_ROWS) {
+        rl = tid < Tq ? lb[tid] : INFINITY;      // queries past the end: p = exp(-inf) = 0
+        rd = tid < Tq ? db[tid] : 0.f;
+    }
+    stQ.store(sQ[0], tid);
+    stO.store(sO[0], tid);
+    if (tid < AM_ROWS) { sL[0][tid] = rl; sD[0][tid] = rd; }
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1, i0 = blk * AM_ROWS;
+        const bool more = blk + 1 < nblk;
+        if (more) {
+            stQ.load(qb, ldq, i0 + AM_ROWS, Tq, tid);
+            stO.load(ob, ldo, i0 + AM_ROWS, Tq, tid);
+            if (tid < AM_ROWS) {
+                const int i = i0 + AM_ROWS + tid;
+                rl = i < Tq ? lb[i] : INFINITY;
+                rd = i < Tq ? db[i] : 0.f;
+            }
+        }
+        // s[it][r] = q(i0 + 16 it + 4 g + r) . k(kj); dp likewise with dout . v
+        f32x4_t s[4], dp[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            s[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dp[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sQ[cur], 16 * it, ks, lane), kf[ks],
+                                                                s[it], 0, 0, 0);
+                dp[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sO[cur], 16 * it, ks, lane), vf[ks],
+                                                                 dp[it], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float4 l4 = *(const float4*)&sL[cur][16 * it + 4 * g];
+            const float4 d4 = *(const float4*)&sD[cur][16 * it + 4 * g];
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = i0 + 16 * it + 4 * g + r;
+                float sv = s[it][r] * scale;
+                if (kmask || (causal && kj > qi)) sv += -1e9f;
+                const float p = __expf(sv - lv[r]);
+                s[it][r] = p;
+                dp[it][r] = p * (dp[it][r] - dl[r]) * scale;    // dS
+            }
+        }
+        // dv^T[d][key] += sum_query dout[query][d] p[query][key]; dk^T likewise with q and dS
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8_t pf = att_pack(s[2 * kk], s[2 * kk + 1]);
+            const bf16x8_t dsf = att_pack(dp[2 * kk], dp[2 * kk + 1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    att_frag_tr<DK>(sO[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), pf, av[nt], 0, 0, 0);
+                ak[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    att_frag_tr<DK>(sQ[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), dsf, ak[nt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            stQ.store(sQ[cur ^ 1], tid);
+            stO.store(sO[cur ^ 1], tid);
+            if (tid < AM_ROWS) { sL[cur ^ 1][tid] = rl; sD[cur ^ 1][tid] = rd; }
+        }
+        __syncthreads();
+    }
+    if (kok) {
+        bf16_t* o1 = dk_ + ((long)b * Tk + kj) * lddk + hh * DK + 4 * g;
+        bf16_t* o2 = dv + ((long)b * Tk + kj) * lddv + hh * DK + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4_t w1 = {(bf16_t)ak[nt][0], (bf16_t)ak[nt][1], (bf16_t)ak[nt][2], (bf16_t)ak[nt][3]};
+            bf16x4_t w2 = {(bf16_t)av[nt][0], (bf16_t)av[nt][1], (bf16_t)av[nt][2], (bf16_t)av[nt][3]};
+            *(bf16x4_t*)(o1 + 16 * nt) = w1;
+            *(bf16x4_t*)(o2 + 16 * nt) = w2;
+        }
+    }
+}

@@ -12,7 +12,7 @@ void athena_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* athena_last_error(void) { return g_err; }
-extern "C" int athena_abi_version(void) { return 1; }
+extern "C" int athena_abi_version(void) { return 2; }
 
 static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     memset(&e, 0, sizeof(e));
@@ -28,6 +28,7 @@ static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     e.aux_dtype = d->aux_dtype;
     e.act = d->act;
     e.atomic = d->split_k > 1;
+    e.bsum = d->b_colsum;
     e.accum = d->accumulate;
     e.alpha = d->alpha;
     e.drop_thresh = d->drop_p > 0.f ? dropout_threshold(d->drop_p) : 0u;
@@ -45,8 +46,8 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     const int b_cols = d->trans_b ? d->K : d->N;
     ATHENA_REQUIRE(d->lda >= a_cols && d->ldb >= b_cols && d->ldc >= d->N, ATHENA_E_SHAPE,
                    "athena_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", d->lda, d->ldb, d->ldc);
-    int split = d->split_k;
-    if (split == 0) split = gemm_auto_split(d->M, d->N, d->K, d->in_dtype);
+    const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->in_dtype, 1, d->split_k == 0);
+    const int split = d->split_k == 0 ? plan.split : d->split_k;
     if (d->split_k != 1)
         ATHENA_REQUIRE(d->out_dtype == ATHENA_F32 && d->act == ATHENA_ACT_NONE && !d->bias && !d->C_pre &&
                            d->drop_p == 0.f && !d->accumulate,
@@ -77,16 +78,57 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     p.seg_base = 0;
     p.split_k = split;
     fill_epilogue(p.epi, d);
+    const bool bf = d->in_dtype == ATHENA_BF16;
+    if (d->b_colsum) {
+        ATHENA_REQUIRE(d->trans_a && !d->trans_b, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum needs trans_a && !trans_b");
+        if (!bf) {
+            // fp32 operands: the column sums come from the stand-alone reduction
+            p.epi.bsum = nullptr;
+            int rc = athena_colsum(d->B, d->in_dtype, d->K, d->N, d->ldb, d->b_colsum, stream);
+            if (rc) return rc;
+        }
+    }
     p.epi.atomic = split > 1;
+    bool reduce = false;
     if (d->split_k == 0 && split > 1) {
-        // auto split: the library zero-fills the fp32 output it is about to accumulate into
-        hipError_t e = (d->ldc == d->N)
-                           ? hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, (hipStream_t)stream)
-                           : hipMemset2DAsync(d->C, sizeof(float) * (size_t)d->ldc, 0, sizeof(float) * (size_t)d->N, d->M, (hipStream_t)stream);
-        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
+        if (d->workspace && (size_t)d->workspace_bytes >= splitk_workspace_bytes(d->M, d->N, split, 1) &&
+            athena_aligned16(d->workspace)) {
+            // partial sums go to the workspace; a second kernel adds them up in a fixed order
+            p.epi.atomic = 2;
+            p.epi.partial = (float*)d->workspace;
+            p.epi.ldp = (d->N + 7) / 8 * 8;
+            reduce = true;
+        } else {
+            // no workspace: fp32 atomics onto a zero-filled output
+            hipError_t e = (d->ldc == d->N)
+                               ? hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, (hipStream_t)stream)
+                               : hipMemset2DAsync(d->C, sizeof(float) * (size_t)d->ldc, 0, sizeof(float) * (size_t)d->N, d->M, (hipStream_t)stream);
+            ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
+            if (p.epi.bsum) {
+                e = hipMemsetAsync(p.epi.bsum, 0, sizeof(float) * (size_t)d->N, (hipStream_t)stream);
+                ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
+            }
+        }
+    } else if (split > 1 && p.epi.bsum) {
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum with an explicit split_k > 1 is not supported");
     }
     p.crow_mode = 0;
-    return launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, (hipStream_t)stream);
+    int rc = launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, plan.bt, (hipStream_t)stream);
+    if (rc) return rc;
+    if (reduce) {
+        const long work = (long)(d->M + 1) * (p.epi.ldp / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)p.epi.partial, split, d->M, d->N, p.epi.ldp, (float*)d->C, d->ldc, 0L, d->alpha,
+                           p.epi.bsum);
+        ATHENA_CHECK_LAUNCH("athena_gemm(split-k reduce)");
+    }
+    return ATHENA_OK;
+}
+
+extern "C" int64_t athena_gemm_workspace_bytes(int M, int N, int K, int in_dtype) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int split = gemm_plan(M, N, K, in_dtype, 1, true).split;
+    return split > 1 ? (int64_t)splitk_workspace_bytes(M, N, split, 1) : 0;
 }
 
 // ------------------------------------------------------------------ Conv2D 3x3 / stride 2 / same
@@ -142,7 +184,8 @@ extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout,
         hipError_t e = hipMemsetAsync(colstats, 0, sizeof(double) * 2 * Cout, (hipStream_t)stream);
         ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_fwd: memset failed");
     }
-    return launch_gemm(p, dtype, false, w_layout == 1, (hipStream_t)stream);
+    return launch_gemm(p, dtype, false, w_layout == 1, gemm_plan(p.M, p.N, 9L * Cin, dtype, 1, false).bt,
+                       (hipStream_t)stream);
 }
 
 extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void* din, int B, int H, int W, int Cin,
@@ -194,29 +237,35 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
             p.epi.alpha = 1.f;
             p.crow_mode = 1;
             p.cr_Ah = Ah; p.cr_Aw = Aw; p.cr_H = H; p.cr_W = W; p.cr_h0 = h0; p.cr_w0 = w0;
-            rc = launch_gemm(p, dtype, false, true, (hipStream_t)stream);
+            rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,
+                             (hipStream_t)stream);
             if (rc) return rc;
         }
     }
     return ATHENA_OK;
 }
 
+extern "C" int64_t athena_conv3x3s2_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    const int rows = B * ((H + 1) / 2) * ((W + 1) / 2);
+    return (int64_t)splitk_workspace_bytes(Cin, Cout, gemm_plan(Cin, Cout, rows, dtype, 9, true).split, 9);
+}
+
 extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* dw_hwio, int B, int H, int W, int Cin,
-                                      int Cout, int dtype, athena_stream_t stream) {
+                                      int Cout, int dtype, void* workspace, int64_t workspace_bytes,
+                                      athena_stream_t stream) {
     int rc = conv_check("athena_conv3x3s2_wgrad", B, H, W, Cin, Cout, dtype);
     if (rc) return rc;
     ATHENA_REQUIRE(in && dout && dw_hwio, ATHENA_E_SHAPE, "athena_conv3x3s2_wgrad: null operand");
     int Ho, Wo, ph, pw;
     same_pad(H, &Ho, &ph);
     same_pad(W, &Wo, &pw);
-    hipError_t e = hipMemsetAsync(dw_hwio, 0, sizeof(float) * 9L * Cin * Cout, (hipStream_t)stream);
-    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_wgrad: memset failed");
     const int rows = B * Ho * Wo;
     // dw[tap][ci][co] = sum_r in(r, tap)[ci] * dout[r][co]: A transposed through the gather, B = dout [K][N]
     // the nine taps are nine independent GEMMs stacked in grid.z; split the long contraction so
     // that taps x splits x output tiles fill the chip
-    int split = (gemm_auto_split(Cin, Cout, rows, dtype) + 8) / 9;
-    if (split < 1) split = 1;
+    const GemmPlan plan = gemm_plan(Cin, Cout, rows, dtype, 9, true);
+    const int split = plan.split;
     GemmProblem<ConvFwdRows> p;
     memset(&p, 0, sizeof(p));
     p.A = in;
@@ -235,8 +284,25 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     p.epi.ldc = Cout;
     p.epi.c_dtype = ATHENA_F32;
     p.epi.alpha = 1.f;
-    p.epi.atomic = 1;
-    rc = launch_gemm(p, dtype, true, false, (hipStream_t)stream);
+    const bool partial = workspace && athena_aligned16(workspace) &&
+                         (size_t)workspace_bytes >= splitk_workspace_bytes(Cin, Cout, split, 9);
+    if (partial) {
+        p.epi.atomic = 2;
+        p.epi.partial = (float*)workspace;
+        p.epi.ldp = (Cout + 7) / 8 * 8;
+    } else {
+        p.epi.atomic = 1;
+        hipError_t e = hipMemsetAsync(dw_hwio, 0, sizeof(float) * 9L * Cin * Cout, (hipStream_t)stream);
+        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_wgrad: memset failed");
+    }
+    rc = launch_gemm(p, dtype, true, false, plan.bt, (hipStream_t)stream);
     if (rc) return rc;
+    if (partial) {
+        const long work = (long)(Cin + 1) * (p.epi.ldp / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), 9), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)p.epi.partial, split, Cin, Cout, p.epi.ldp, dw_hwio, Cout, (long)Cin * Cout, 1.f,
+                           (float*)nullptr);
+        ATHENA_CHECK_LAUNCH("athena_conv3x3s2_wgrad(split-k reduce)");
+    }
     return ATHENA_OK;
 }

@@ -23,10 +23,13 @@ struct Epilogue {
     const void* aux;
     const uint64_t* rng_state;
     double* colsum;    // optional [2*N] per-column sum / sum of squares of the stored values
+    float* partial;    // split-K slabs [grid.z][M + 1][ldp] (row M: column sums of B) when atomic == 2
+    float* bsum;       // optional [N]: sum over k of B(k, n), taken by the first row of workgroups
+    int ldp;
     int ldc, ldaux;
     int c_dtype, aux_dtype;
     int act;
-    int atomic;
+    int atomic;        // 0: single writer; 1: fp32 atomics onto C; 2: raw partial sums into ``partial``
     int accum;
     float alpha;
     float drop_scale;
@@ -312,6 +315,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
 
     uint4 ra[NCH], rb[NCH];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // column sums of B (bias gradient of a weight-gradient GEMM): the first row of workgroups adds
+    // up the B pieces it stages anyway; a thread keeps the same 8 columns in every piece
+    const bool want_bsum = !TB && p.epi.bsum != nullptr && blockIdx.x == 0;
+    float bs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bs[r] = 0.f;
 
     auto load_tile = [&](int t) {
         const int seg = t / tiles_per_seg;
@@ -369,6 +378,14 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
     if (t_begin < t_end) {
         load_tile(t_begin);
         store_tile(0);
+        if (!TB && want_bsum) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const bf16x8_t h = __builtin_bit_cast(bf16x8_t, rb[i]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bs[r] += (float)h[r];
+            }
+        }
         __syncthreads();
         int cur = 0;
         for (int t = t_begin; t < t_end; ++t) {
@@ -396,10 +413,39 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
                     for (int j = 0; j < WT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
             }
-            if (more) store_tile(cur ^ 1);
+            if (more) {
+                store_tile(cur ^ 1);
+                if (!TB && want_bsum) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const bf16x8_t h = __builtin_bit_cast(bf16x8_t, rb[i]);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) bs[r] += (float)h[r];
+                    }
+                }
+            }
             __syncthreads();
             cur ^= 1;
         }
+    }
+    if (!TB && want_bsum) {
+        // (the first tile's pieces were added before the loop, see below)
+        float* red = (float*)lds;                 // [256 threads][8], 8 KB
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[tid * 8 + r] = bs[r];
+        __syncthreads();
+        if (tid < BT) {
+            // column tid of the tile = chunk tid / 8, element tid % 8; owners are threads == chunk (mod NC)
+            float t = 0.f;
+            for (int o = tid >> 3; o < 256; o += NC) t += red[o * 8 + (tid & 7)];
+            const int n = bn + tid;
+            if (n < p.N) {
+                if (p.epi.atomic == 2) p.epi.partial[((long)blockIdx.z * (p.M + 1) + p.M) * p.epi.ldp + n] = t;
+                else if (p.epi.atomic == 1) atomicAdd(p.epi.bsum + n, t);
+                else p.epi.bsum[n] = t;
+            }
+        }
+        __syncthreads();
     }
 
     // epilogue.  Element r of acc[i][j] is C[m = m0 + (lane & 15)][n = n0 + 4*(lane >> 4) + r].  The
@@ -436,6 +482,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
         const int mo = out_row(p, m);
         const int nv = min(8, p.N - n);
         const long ci = (long)mo * p.epi.ldc + n;
+        if (p.epi.atomic == 2) {
+            // raw partial sums; ldp is a multiple of 8 and columns past N hold zeros
+            float* c = p.epi.partial + ((long)blockIdx.z * (p.M + 1) + mo) * p.epi.ldp + n;
+            *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            continue;
+        }
         if (p.epi.atomic) {
             float* c = (float*)p.epi.C + coff + ci;
 #pragma unroll
@@ -502,18 +555,26 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
         }
     }
     if (p.epi.colsum) {
-        // threads with equal (tid % CPR) own the same 8 columns: fold inside the wave, then one
-        // fp64 atomic per column per wave
+        // threads with equal (tid % CPR) own the same 8 columns: fold inside the wave, then across
+        // the four waves through LDS, so a block issues one fp64 atomic per column and statistic
+        __syncthreads();                              // every thread is done reading sC
+        float* red = (float*)lds;                     // [4 waves][BT columns][2]
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             float sm = csum[r], q = csq[r];
 #pragma unroll
             for (int o = CPR; o < 64; o <<= 1) { sm += __shfl_xor(sm, o, 64); q += __shfl_xor(q, o, 64); }
-            const int n = bn + (tid % CPR) * 8 + r;
-            if ((lane / CPR) == 0 && n < p.N) {
-                atomicAdd(p.epi.colsum + n, (double)sm);
-                atomicAdd(p.epi.colsum + p.N + n, (double)q);
+            if (lane < CPR) {
+                red[(wave * BT + lane * 8 + r) * 2] = sm;
+                red[(wave * BT + lane * 8 + r) * 2 + 1] = q;
             }
+        }
+        __syncthreads();
+        if (tid < 2 * BT) {
+            const int col = tid >> 1, which = tid & 1;
+            const float t = red[(0 * BT + col) * 2 + which] + red[(1 * BT + col) * 2 + which] +
+                            red[(2 * BT + col) * 2 + which] + red[(3 * BT + col) * 2 + which];
+            if (bn + col < p.N) atomicAdd(p.epi.colsum + which * p.N + bn + col, (double)t);
         }
     }
 }
@@ -610,6 +671,10 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
         for (int j = 0; j < 4; ++j) {
             const int n = bn + tx * 4 + j;
             if (n < p.N) {
+                if (p.epi.atomic == 2) {
+                    p.epi.partial[((long)blockIdx.z * (p.M + 1) + mo) * p.epi.ldp + n] = acc[i][j];
+                    continue;
+                }
                 epilogue_store(p.epi, mo, n, acc[i][j], key, coff);
                 if (p.epi.colsum) {
                     float v = acc[i][j] * p.epi.alpha;
@@ -619,6 +684,46 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
             }
         }
     }
+}
+
+// Second pass of a split-K product whose workgroups wrote raw partial sums: adds the ``split``
+// slabs of each batch in a fixed order (bit-reproducible, no atomics, no zero-fill of C) and
+// writes C = alpha * sum.  Row M of a slab carries the column sums of B and goes to ``bsum``.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split, int M, int N,
+                                                            int ldp, float* __restrict__ C, int ldc,
+                                                            long c_batch_stride, float alpha,
+                                                            float* __restrict__ bsum) {
+    const int q = ldp >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(idx / q), n = (int)(idx % q) * 4;
+    if (row > M || n >= N || (row == M && !bsum)) return;
+    const long slab = (long)(M + 1) * ldp;
+    const float* src = partial + (long)blockIdx.y * split * slab + (long)row * ldp + n;
+    float4 s = *(const float4*)src;
+    for (int i = 1; i < split; ++i) {
+        const float4 t = *(const float4*)(src + i * slab);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const float v[4] = {s.x, s.y, s.z, s.w};
+    if (row == M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) bsum[n + r] = v[r];
+        return;
+    }
+    float* c = C + (long)blockIdx.y * c_batch_stride + (long)row * ldc + n;
+    if (n + 3 < N && (ldc & 3) == 0 && ((((uintptr_t)C) & 15) == 0) && (c_batch_stride & 3) == 0) {
+        *(float4*)c = make_float4(v[0] * alpha, v[1] * alpha, v[2] * alpha, v[3] * alpha);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) c[r] = v[r] * alpha;
+    }
+}
+
+static inline size_t splitk_workspace_bytes(int M, int N, int split, int zbatch) {
+    const size_t ldp = (size_t)(N + 7) / 8 * 8;
+    return sizeof(float) * (size_t)(zbatch > 1 ? zbatch : 1) * split * (size_t)(M + 1) * ldp;
 }
 
 // number of workgroups a launch would use with tile edge ``bt``
@@ -634,13 +739,51 @@ static void launch_mfma(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_
     else hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, true, WT>), grid, dim3(256), 0, stream, p);
 }
 
-// tile edge the bf16 path will use for an M x N output
-static inline int gemm_mfma_tile(int M, int N) { return gemm_tiles(M, N, 128) >= 192 ? 128 : 64; }
+// Tile edge and split-K factor for an M x N output with ``k_elems`` contraction elements and
+// ``zbatch`` independent problems.  128x128 tiles do twice the MFMA work per LDS byte of 64x64
+// tiles, so they are used whenever they still fill the chip (~256 CUs, two workgroups each) --
+// on their own, or together with a K split that leaves each workgroup at least 8 k-tiles.
+struct GemmPlan { int bt, split; };
 
+static inline GemmPlan gemm_plan(int M, int N, long k_elems, int in_dtype, int zbatch, bool may_split) {
+    GemmPlan pl;
+    if (zbatch < 1) zbatch = 1;
+    if (in_dtype != ATHENA_BF16) {
+        const long tiles = gemm_tiles(M, N, GV_BM) * zbatch;
+        const long ktiles = (k_elems + GV_BK - 1) / GV_BK;
+        long split = may_split ? 512 / (tiles > 0 ? tiles : 1) : 1;
+        if (split > ktiles / 4) split = ktiles / 4;
+        if (split < 1) split = 1;
+        if (split > 256) split = 256;
+        pl.bt = GV_BM;
+        pl.split = (int)split;
+        return pl;
+    }
+    const long ktiles = (k_elems + GM_BK - 1) / GM_BK;
+    const long t128 = gemm_tiles(M, N, 128) * zbatch;
+    long s128 = may_split ? (512 + t128 - 1) / t128 : 1;
+    if (s128 > ktiles / 8) s128 = ktiles / 8;
+    if (s128 < 1) s128 = 1;
+    if (M > 64 && N > 64 && (t128 >= 192 || t128 * s128 >= 256)) {
+        pl.bt = 128;
+        pl.split = t128 >= 384 ? 1 : (int)s128;
+        return pl;
+    }
+    const long t64 = gemm_tiles(M, N, 64) * zbatch;
+    long s64 = may_split ? 512 / (t64 > 0 ? t64 : 1) : 1;
+    if (s64 > ktiles / 4) s64 = ktiles / 4;
+    if (s64 < 1) s64 = 1;
+    if (s64 > 256) s64 = 256;
+    pl.bt = 64;
+    pl.split = (int)s64;
+    return pl;
+}
+
+// ``bt``: tile edge chosen by gemm_plan (bf16 path)
 template <class AMap>
-static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool tb, hipStream_t stream) {
+static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool tb, int bt, hipStream_t stream) {
     if (in_dtype == ATHENA_BF16) {
-        if (gemm_mfma_tile(p.M, p.N) == 128) launch_mfma<AMap, 4>(p, ta, tb, stream);
+        if (bt == 128) launch_mfma<AMap, 4>(p, ta, tb, stream);
         else launch_mfma<AMap, 2>(p, ta, tb, stream);
     } else {
         dim3 grid((p.M + GV_BM - 1) / GV_BM, (p.N + GV_BN - 1) / GV_BN, p.split_k * (p.zbatch > 1 ? p.zbatch : 1));
@@ -651,18 +794,4 @@ static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool t
     }
     ATHENA_CHECK_LAUNCH("gemm");
     return ATHENA_OK;
-}
-
-// split-K factor for an output of M x N with ``k_elems`` contraction elements: enough
-// workgroups to fill the chip (~512) without multiplying the atomic traffic more than needed
-static inline int gemm_auto_split(int M, int N, long k_elems, int in_dtype) {
-    const int bt = in_dtype == ATHENA_BF16 ? gemm_mfma_tile(M, N) : GV_BM;
-    const int bk = in_dtype == ATHENA_BF16 ? GM_BK : GV_BK;
-    const long tiles = gemm_tiles(M, N, bt);
-    const long ktiles = (k_elems + bk - 1) / bk;
-    long split = 512 / (tiles > 0 ? tiles : 1);
-    if (split > ktiles / 4) split = ktiles / 4;     // at least 4 k-tiles per split
-    if (split < 1) split = 1;
-    if (split > 256) split = 256;
-    return (int)split;
 }

@@ -62,8 +62,8 @@ def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=
 def lin_bwd_w(x, dy, M, dense, ldx, lddy):
     """kernel.grad = x^T @ dy ; bias.grad = column sums of dy."""
     K, N = dense.in_features, dense.out_features
-    ops.gemm(x, dy, dense.kernel.grad, K, N, M, trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0)
-    ops.colsum(dy, M, N, lddy, dense.bias.grad)
+    ops.gemm(x, dy, dense.kernel.grad, K, N, M, trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0,
+             b_colsum=dense.bias.grad)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -88,6 +88,8 @@ def bench_conv():
     fl = 2.0 * 9 * C * C * B * Ho * Wo
     t = timeit(lambda: ops.conv3x3s2_fwd(x, wt, 1, out, B, H, W, C, C, st), reps=5)
     print("fwd   %8.1f us %7.1f TFLOP/s" % (t * 1e6, fl / t / 1e12))
+    t = timeit(lambda: ops.conv3x3s2_fwd(x, wt, 1, out, B, H, W, C, C, None), reps=5)
+    print("fwd (no column statistics) %8.1f us %7.1f TFLOP/s" % (t * 1e6, fl / t / 1e12))
     dy = torch.randn_like(out)
     din = torch.empty_like(x)
     t = timeit(lambda: ops.conv3x3s2_dgrad(dy, w, din, B, H, W, C, C), reps=5)

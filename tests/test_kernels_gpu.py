@@ -82,6 +82,28 @@ def test_gemm_epilogues(ops, cd):
 
 
 @pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("rows,K,N,ldx,ldy", [(3000, 72, 48, 72, 48), (8000, 256, 256, 256, 256),
+                                              (1056, 256, 4233, 256, 4240), (500, 1024, 64, 1024, 64),
+                                              (4000, 136, 100, 136, 104), (64, 5120, 256, 5120, 256)])
+def test_gemm_weight_gradient(ops, cd, rows, K, N, ldx, ldy):
+    """x^T.dy with automatic split-K through the workspace, bias gradient from the same launch."""
+    g = torch.Generator().manual_seed(rows + K + N)
+    X = torch.randn(rows, ldx, generator=g, dtype=torch.float64)
+    dY = torch.randn(rows, ldy, generator=g, dtype=torch.float64)
+    Xr, dYr = rounded(X, cd)[:, :K], rounded(dY, cd)[:, :N]
+    G = torch.full((K, N), float("nan"), dtype=torch.float32, device=dev())
+    gb = torch.full((N,), float("nan"), dtype=torch.float32, device=dev())
+    x_d, dy_d = to_cd(X, cd), to_cd(dY, cd)
+    ops.gemm(x_d, dy_d, G, K, N, rows, trans_a=True, trans_b=False, lda=ldx, ldb=ldy, split_k=0, b_colsum=gb)
+    assert_close(G, Xr.t() @ dYr, 2e-5, "weight gradient")
+    assert_close(gb, dYr.sum(0), 2e-5, "bias gradient")
+    G2, gb2 = torch.empty_like(G), torch.empty_like(gb)
+    ops.gemm(x_d, dy_d, G2, K, N, rows, trans_a=True, trans_b=False, lda=ldx, ldb=ldy, split_k=0, b_colsum=gb2)
+    if cd == torch.bfloat16:      # fixed-order reduction: bit-reproducible
+        assert torch.equal(G, G2) and torch.equal(gb, gb2)
+
+
+@pytest.mark.parametrize("cd", DTYPES)
 def test_gemm_dropout_consistency(ops, cd):
     """Same site + state gives the same mask in the forward and the backward epilogue."""
     M, N, K = 96, 64, 32
@@ -178,7 +200,9 @@ def _attn_ref(q, k, v, key_mask, causal, scale):
 @pytest.mark.parametrize("cd", DTYPES)
 @pytest.mark.parametrize("B,h,Tq,Tk,dk,causal", [(2, 4, 37, 37, 8, False), (3, 2, 19, 19, 32, True),
                                                 (2, 4, 33, 70, 64, False), (1, 8, 130, 130, 32, False),
-                                                (2, 2, 5, 5, 16, True)])
+                                                (2, 2, 5, 5, 16, True), (2, 2, 250, 250, 64, False),
+                                                (1, 2, 33, 250, 64, False), (1, 1, 70, 70, 128, True),
+                                                (2, 4, 200, 200, 64, True), (1, 2, 64, 128, 32, False)])
 def test_mha(ops, cd, B, h, Tq, Tk, dk, causal):
     g = torch.Generator().manual_seed(B * 100 + Tq + dk)
     d = h * dk
@@ -226,6 +250,20 @@ def test_mha_fully_masked_row_is_uniform(ops):
     lse = torch.empty(B, h, T, device=dev())
     ops.mha_fwd(q, k, v, dk, dk, dk, km, False, B, h, T, T, dk, 1.0, out, dk, lse)
     assert_close(out[0, 0, 0], v[0, :, 0].mean(0), 1e-5, "uniform")
+
+
+def test_mha_fully_masked_row_is_uniform_bf16(ops):
+    """Same property on the matrix-core kernels (bf16, head size 64, more keys than one block)."""
+    B, h, T, dk = 2, 2, 100, 64
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(B, T, h, dk, generator=g).to(dev()).to(torch.bfloat16) for _ in range(3))
+    km = torch.ones(B, T, dtype=torch.uint8, device=dev())
+    km[1, :40] = 0
+    out = torch.empty_like(q)
+    lse = torch.empty(B, h, T, device=dev())
+    ops.mha_fwd(q, k, v, h * dk, h * dk, h * dk, km, False, B, h, T, T, dk, 0.125, out, h * dk, lse)
+    assert_close(out[0, 5, 1], v[0, :, 1].float().mean(0), 1e-2, "uniform")
+    assert bool(torch.isfinite(out.float()).all())
 
 
 # ------------------------------------------------------------------------------------------ conv / BN
