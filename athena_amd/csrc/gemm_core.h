@@ -117,6 +117,7 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n,
 // prep(r) decodes row r once; off(row, seg) = element offset of that row within segment ``seg``
 // (or -1 when the row is all zeros there); step(row, d) moves to row r + d.
 struct PlainRows {
+    static constexpr bool kCanMiss = false;    // off() never reports an all-zero row
     long ld;
     struct Row { long base; };
     __device__ __forceinline__ Row prep(int r) const { return Row{(long)r * ld}; }
@@ -128,6 +129,7 @@ struct PlainRows {
 // [B, H, W, C].  Row r = (b, ho, wo); segment = tap (kh*3+kw); the row is the C-vector at
 // input pixel (2*ho - pad_h + kh, 2*wo - pad_w + kw), zero outside the image.
 struct ConvFwdRows {
+    static constexpr bool kCanMiss = true;
     int H, W, C, Ho, Wo, pad_h, pad_w;
     struct Row { int b, ho, wo; };
     __device__ __forceinline__ Row prep(int r) const {
@@ -156,6 +158,7 @@ struct ConvFwdRows {
 // that reach this class; the row is the Cout-vector of the output gradient at
 // (ah + dh[s], aw + dw[s]).
 struct ConvDgradRows {
+    static constexpr bool kCanMiss = true;
     int Ho, Wo, Co, Ah, Aw;     // Ah x Aw = pixels of this class per image
     int dh[4], dw[4];
     struct Row { int b, ah, aw; };
@@ -260,7 +263,7 @@ __device__ __forceinline__ bf16x8_t lds_frag_tr(const bf16_t* img, int col0, int
 }
 
 template <class AMap, bool TA, bool TB, int WT>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) {
     // independent problems stacked in grid.z (the kernel argument itself is never written:
     // a modified by-value struct would be spilled to scratch memory)
     const int zb = p.zbatch > 1 ? (int)(blockIdx.z / p.split_k) : 0;
@@ -295,25 +298,31 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
         for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // per-thread staging pieces.  Row-major operand: piece c -> (row c/8, k-chunk c%8);
-    // transposed operand: piece c -> (k-row c/(BT/8), column chunk c%(BT/8)).
+    // transposed operand: piece c -> (k-row c/NC, column chunk c%NC).  Rows and column chunks
+    // outside the matrix are clamped to the last valid one rather than zero-filled: they only feed
+    // output rows / columns that are never stored, and the loads stay free of branches.
     typename AMap::Row arow[NCH];
-    bool avalid[NCH];
+    int acol[NCH];                 // element offset inside the A row: k-chunk, or the clamped m-chunk
+    const bf16_t* pb[NCH];         // B piece at k = 0 of a segment
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = tid + 256 * i;
         if (!TA) {
-            const int m = bm + (c >> 3);
-            avalid[i] = m < p.M;
-            arow[i] = p.amap.prep(avalid[i] ? m : 0);
+            arow[i] = p.amap.prep(min(bm + (c >> 3), p.M - 1));
+            acol[i] = (c & 7) * 8;
         } else {
             // rows follow the contraction index: start at the first tile of this split (nseg == 1)
-            const int k = t_begin * GM_BK + c / (BT / 8);
-            avalid[i] = true;
-            arow[i] = p.amap.prep(k < p.kseg ? k : 0);
+            arow[i] = p.amap.prep(min(t_begin * GM_BK + c / NC, p.kseg - 1));
+            acol[i] = min(bm + (c % NC) * 8, ((p.M + 7) & ~7) - 8);
         }
+        if (TB) pb[i] = B + (long)min(bn + (c >> 3), p.N - 1) * p.ldb + (c & 7) * 8;
+        else pb[i] = B + (long)(c / NC) * p.ldb + min(bn + (c % NC) * 8, ((p.N + 7) & ~7) - 8);
     }
 
-    uint4 ra[NCH], rb[NCH];
+    // two register staging sets: while tile t is multiplied out of LDS, tile t+1 waits in one set
+    // for its turn to be written to the other LDS stage and the loads of tile t+2 are in flight
+    // into the other set, so a global load has two tile-times to arrive
+    uint4 ra0[NCH], rb0[NCH], ra1[NCH], rb1[NCH];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     // column sums of B (bias gradient of a weight-gradient GEMM): the first row of workgroups adds
     // up the B pieces it stages anyway; a thread keeps the same 8 columns in every piece
@@ -322,39 +331,47 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) bs[r] = 0.f;
 
-    auto load_tile = [&](int t) {
-        const int seg = t / tiles_per_seg;
+    auto load_tile = [&](int t, uint4 (&ra)[NCH], uint4 (&rb)[NCH]) {
+        const bool live = t < t_end;
+        const int seg = live ? t / tiles_per_seg : 0;
         const int k0 = (t - seg * tiles_per_seg) * GM_BK;
+        const long bseg = p.b_seg_off[seg];
+        // Zero-filling is done by AND-ing the loaded words with a mask after an always-valid load
+        // (a select between a load and zero would be turned into a load through a selected pointer
+        // to a zero kept in scratch memory).
+        if (live && k0 + GM_BK <= p.kseg) {
+            // whole tile inside the contraction range (the common case)
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            if (!TA) {
-                const int k = k0 + (c & 7) * 8;
-                uint4 v = zero4;
-                if (avalid[i] && k < p.kseg) {
-                    const long o = p.amap.off(arow[i], seg_base + seg);
-                    if (o >= 0) v = *(const uint4*)(A + o + k);
+            for (int i = 0; i < NCH; ++i) {
+                long o = p.amap.off(arow[i], seg_base + seg);
+                uint32_t keep = 0xffffffffu;
+                if (AMap::kCanMiss) {
+                    keep = o >= 0 ? 0xffffffffu : 0u;
+                    o = o >= 0 ? o : 0;
                 }
+                uint4 v = *(const uint4*)(A + o + (TA ? acol[i] : k0 + acol[i]));
+                if (AMap::kCanMiss) { v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep; }
                 ra[i] = v;
-            } else {
-                const int k = k0 + c / (BT / 8), m = bm + (c % (BT / 8)) * 8;
-                uint4 v = zero4;
-                if (m < p.M && k < p.kseg) {
-                    const long o = p.amap.off(arow[i], seg_base + seg);
-                    if (o >= 0) v = *(const uint4*)(A + o + m);
-                }
-                ra[i] = v;
+                rb[i] = *(const uint4*)(pb[i] + bseg + (TB ? (long)k0 : (long)k0 * p.ldb));
             }
-            if (TB) {
-                const int n = bn + (c >> 3), k = k0 + (c & 7) * 8;
-                uint4 v = zero4;
-                if (n < p.N && k < p.kseg) v = *(const uint4*)(B + p.b_seg_off[seg] + (long)n * p.ldb + k);
-                rb[i] = v;
-            } else {
-                const int k = k0 + c / (BT / 8), n = bn + (c % (BT / 8)) * 8;
-                uint4 v = zero4;
-                if (n < p.N && k < p.kseg) v = *(const uint4*)(B + p.b_seg_off[seg] + (long)k * p.ldb + n);
-                rb[i] = v;
+        } else {
+            // the last, partial tile of a segment, or a tile index past the end (all zeros)
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i;
+                const int ka = k0 + (TA ? c / NC : acol[i]);
+                const int kb = k0 + (TB ? (c & 7) * 8 : c / NC);
+                const long o = p.amap.off(arow[i], seg_base + seg);
+                const bool oka = live && ka < p.kseg && o >= 0;
+                const bool okb = live && kb < p.kseg;
+                const uint32_t keepa = oka ? 0xffffffffu : 0u, keepb = okb ? 0xffffffffu : 0u;
+                const long offa = oka ? o + (TA ? acol[i] : ka) : 0;
+                const bf16_t* ptrb = okb ? pb[i] + bseg + (TB ? (long)k0 : (long)k0 * p.ldb) : B;
+                uint4 va = *(const uint4*)(A + offa), vb = *(const uint4*)ptrb;
+                va.x &= keepa; va.y &= keepa; va.z &= keepa; va.w &= keepa;
+                vb.x &= keepb; vb.y &= keepb; vb.z &= keepb; vb.w &= keepb;
+                ra[i] = va;
+                rb[i] = vb;
             }
         }
         if (TA) {
@@ -362,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
             for (int i = 0; i < NCH; ++i) p.amap.step(arow[i], GM_BK);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const uint4 (&ra)[NCH], const uint4 (&rb)[NCH]) {
         bf16_t* sA = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* sB = sA + A_ELEMS;
 #pragma unroll
@@ -373,11 +390,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
             if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = rb[i];
             else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = rb[i];
         }
-    };
-
-    if (t_begin < t_end) {
-        load_tile(t_begin);
-        store_tile(0);
         if (!TB && want_bsum) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -386,50 +398,54 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
                 for (int r = 0; r < 8; ++r) bs[r] += (float)h[r];
             }
         }
+    };
+    auto multiply_tile = [&](int buf) {
+        const bf16_t* sA = lds + buf * (A_ELEMS + B_ELEMS);
+        const bf16_t* sB = sA + A_ELEMS;
+        const int fr = lane & 15, fk = (lane >> 4) * 8;
+#pragma unroll
+        for (int ks = 0; ks < GM_BK; ks += 32) {
+            bf16x8_t af[WT], bfr[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                const int m0 = wm * 16 * WT + i * 16;
+                af[i] = TA ? lds_frag_tr<NC>(sA, m0, ks, lane) : lds_frag_rows(sA, m0 + fr, ks + fk);
+            }
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int n0 = wn * 16 * WT + j * 16;
+                bfr[j] = TB ? lds_frag_rows(sB, n0 + fr, ks + fk) : lds_frag_tr<NC>(sB, n0, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (t_begin < t_end) {
+        // tiles are taken in pairs; a tile index past t_end loads as zeros and multiplies to nothing,
+        // which keeps the loop body free of exits (one accumulator set, fixed register roles)
+        load_tile(t_begin, ra0, rb0);
+        load_tile(t_begin + 1, ra1, rb1);
+        store_tile(0, ra0, rb0);
         __syncthreads();
-        int cur = 0;
-        for (int t = t_begin; t < t_end; ++t) {
-            const bool more = (t + 1 < t_end);
-            if (more) load_tile(t + 1);
-            const bf16_t* sA = lds + cur * (A_ELEMS + B_ELEMS);
-            const bf16_t* sB = sA + A_ELEMS;
-            const int fr = lane & 15, fk = (lane >> 4) * 8;
-#pragma unroll
-            for (int ks = 0; ks < GM_BK; ks += 32) {
-                bf16x8_t af[WT], bfr[WT];
-#pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    const int m0 = wm * 16 * WT + i * 16;
-                    af[i] = TA ? lds_frag_tr<NC>(sA, m0, ks, lane) : lds_frag_rows(sA, m0 + fr, ks + fk);
-                }
-#pragma unroll
-                for (int j = 0; j < WT; ++j) {
-                    const int n0 = wn * 16 * WT + j * 16;
-                    bfr[j] = TB ? lds_frag_rows(sB, n0 + fr, ks + fk) : lds_frag_tr<NC>(sB, n0, ks, lane);
-                }
-#pragma unroll
-                for (int i = 0; i < WT; ++i)
-#pragma unroll
-                    for (int j = 0; j < WT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            }
-            if (more) {
-                store_tile(cur ^ 1);
-                if (!TB && want_bsum) {
-#pragma unroll
-                    for (int i = 0; i < NCH; ++i) {
-                        const bf16x8_t h = __builtin_bit_cast(bf16x8_t, rb[i]);
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) bs[r] += (float)h[r];
-                    }
-                }
-            }
+#pragma nounroll
+        for (int t = t_begin; t < t_end; t += 2) {
+            // LDS stage 0 holds tile t, set 1 holds tile t+1
+            load_tile(t + 2, ra0, rb0);
+            multiply_tile(0);
+            store_tile(1, ra1, rb1);
             __syncthreads();
-            cur ^= 1;
+            // LDS stage 1 holds tile t+1, set 0 holds tile t+2
+            load_tile(t + 3, ra1, rb1);
+            multiply_tile(1);
+            store_tile(0, ra0, rb0);
+            __syncthreads();
         }
     }
     if (!TB && want_bsum) {
-        // (the first tile's pieces were added before the loop, see below)
         float* red = (float*)lds;                 // [256 threads][8], 8 KB
 #pragma unroll
         for (int r = 0; r < 8; ++r) red[tid * 8 + r] = bs[r];
@@ -449,112 +465,175 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
     }
 
     // epilogue.  Element r of acc[i][j] is C[m = m0 + (lane & 15)][n = n0 + 4*(lane >> 4) + r].  The
-    // tile is first parked in LDS (fp32, 16-byte chunks XOR-swizzled by row), then every thread
-    // walks whole 8-column pieces of rows: bias/aux are read and C is written with 16-byte
-    // accesses along rows, and the code stays one small loop instead of WT*WT unrolled copies.
+    // tile is first parked in LDS (fp32, 16-byte chunks XOR-swizzled by row); then every thread
+    // walks one 8-column piece down the rows of the tile, so bias and column statistics stay in
+    // registers, C is written with 16-byte accesses along rows, and everything that does not
+    // depend on the element (activation kind, dropout on/off, output type) is decided once.
     float* sC = (float*)lds;                      // BT*BT floats fit exactly in the two stages
-    const int fq = lane >> 4, fr = lane & 15;
+    {
+        const int fq = lane >> 4, fr = lane & 15;
 #pragma unroll
-    for (int i = 0; i < WT; ++i) {
+        for (int i = 0; i < WT; ++i) {
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
-            const int row = wm * 16 * WT + i * 16 + fr;
-            const int chunk = (wn * 16 * WT + j * 16) / 4 + fq;
-            *(f32x4_t*)(sC + row * BT + ((chunk ^ (row & 7)) * 4)) = acc[i][j];
+            for (int j = 0; j < WT; ++j) {
+                const int row = wm * 16 * WT + i * 16 + fr;
+                const int chunk = (wn * 16 * WT + j * 16) / 4 + fq;
+                *(f32x4_t*)(sC + row * BT + ((chunk ^ (row & 7)) * 4)) = acc[i][j];
+            }
         }
     }
     __syncthreads();
-    uint64_t key = 0;
-    if (p.epi.drop_thresh) key = rng_key(p.epi.rng_state, p.epi.rng_site);
     constexpr int CPR = BT / 8;                   // 8-column pieces per tile row
-    const bool vec8 = (p.epi.ldc % 8 == 0) && ((((uintptr_t)p.epi.C) & 15) == 0) &&
-                      (!p.epi.C_pre || (((uintptr_t)p.epi.C_pre) & 15) == 0);
-    float csum[8], csq[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { csum[r] = 0.f; csq[r] = 0.f; }
-    for (int idx = tid; idx < BT * CPR; idx += 256) {
-        const int row = idx / CPR, c8 = idx % CPR;     // 256 % CPR == 0: a thread keeps its columns
-        const int m = bm + row, n = bn + c8 * 8;
-        if (m >= p.M || n >= p.N) continue;
+    constexpr int RSTEP = 256 / CPR;              // rows between two pieces of a thread
+    const int c8 = tid % CPR, row0 = tid / CPR;
+    const int n = bn + c8 * 8;
+    const int nv = min(8, p.N - n);               // <= 0: this thread's columns are outside the matrix
+    const Epilogue& e = p.epi;
+    auto read_piece = [&](int row, float (&v)[8]) {
         const f32x4_t x0 = *(const f32x4_t*)(sC + row * BT + (((2 * c8) ^ (row & 7)) * 4));
         const f32x4_t x1 = *(const f32x4_t*)(sC + row * BT + (((2 * c8 + 1) ^ (row & 7)) * 4));
-        float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-        const int mo = out_row(p, m);
-        const int nv = min(8, p.N - n);
-        const long ci = (long)mo * p.epi.ldc + n;
-        if (p.epi.atomic == 2) {
-            // raw partial sums; ldp is a multiple of 8 and columns past N hold zeros
-            float* c = p.epi.partial + ((long)blockIdx.z * (p.M + 1) + mo) * p.epi.ldp + n;
-            *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            continue;
-        }
-        if (p.epi.atomic) {
-            float* c = (float*)p.epi.C + coff + ci;
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (r < nv) atomicAdd(c + r, v[r] * p.epi.alpha);
-            continue;
-        }
-        const long ai = (long)mo * p.epi.ldaux + n;
-        float pre[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            v[r] = (r < nv) ? epilogue_value(p.epi, ci + r, ai + r, n + r, v[r], key, &pre[r]) : 0.f;
-        if (p.epi.colsum) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float sv = v[r];
-                if (p.epi.c_dtype == ATHENA_BF16) sv = (float)(bf16_t)sv;
-                if (r < nv) { csum[r] += sv; csq[r] += sv * sv; }
-            }
-        }
-        if (nv == 8 && vec8) {
-            if (p.epi.c_dtype == ATHENA_BF16) {
-                bf16_t* c = (bf16_t*)p.epi.C + ci;
-                if (p.epi.C_pre) {
-                    bf16x8_t pv;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) pv[r] = (bf16_t)pre[r];
-                    *(bf16x8_t*)((bf16_t*)p.epi.C_pre + ci) = pv;
-                }
-                if (p.epi.accum) {
-                    const bf16x8_t old = *(const bf16x8_t*)c;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += (float)old[r];
-                }
-                bf16x8_t o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-                *(bf16x8_t*)c = o;
-            } else {
-                float* c = (float*)p.epi.C + ci;
-                if (p.epi.C_pre) {
-                    float* cp = (float*)p.epi.C_pre + ci;
-                    *(float4*)cp = make_float4(pre[0], pre[1], pre[2], pre[3]);
-                    *(float4*)(cp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
-                }
-                if (p.epi.accum) {
-                    const float4 o0 = *(const float4*)c, o1 = *(const float4*)(c + 4);
-                    v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
-                    v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
-                }
+        v[0] = x0[0]; v[1] = x0[1]; v[2] = x0[2]; v[3] = x0[3];
+        v[4] = x1[0]; v[5] = x1[1]; v[6] = x1[2]; v[7] = x1[3];
+    };
+    if (e.atomic == 2) {
+        // raw partial sums; ldp is a multiple of 8 and columns past N hold zeros
+        if (nv > 0) {
+            for (int row = row0; row < BT && bm + row < p.M; row += RSTEP) {
+                float v[8];
+                read_piece(row, v);
+                float* c = e.partial + ((long)blockIdx.z * (p.M + 1) + out_row(p, bm + row)) * e.ldp + n;
                 *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
-        } else {
+        }
+        return;
+    }
+    if (e.atomic == 1) {
+        if (nv > 0) {
+            for (int row = row0; row < BT && bm + row < p.M; row += RSTEP) {
+                float v[8];
+                read_piece(row, v);
+                float* c = (float*)e.C + coff + (long)out_row(p, bm + row) * e.ldc + n;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r < nv) atomicAdd(c + r, v[r] * e.alpha);
+            }
+        }
+        return;
+    }
+    float csum[8], csq[8], b8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        csum[r] = 0.f;
+        csq[r] = 0.f;
+        b8[r] = (e.bias && r < nv) ? e.bias[n + r] : 0.f;
+    }
+    const bool bf_out = e.c_dtype == ATHENA_BF16;
+    const bool vec8 = nv == 8 && (e.ldc % 8 == 0) && ((((uintptr_t)e.C) & 15) == 0) &&
+                      (!e.C_pre || (((uintptr_t)e.C_pre) & 15) == 0);
+    const bool aux_vec = nv == 8 && e.aux && (e.ldaux % 8 == 0) && ((((uintptr_t)e.aux) & 15) == 0);
+    uint64_t key = 0;
+    if (e.drop_thresh) key = rng_key(e.rng_state, e.rng_site);
+    if (nv > 0) {
+        for (int row = row0; row < BT && bm + row < p.M; row += RSTEP) {
+            float v[8], pre[8];
+            read_piece(row, v);
+            const int mo = out_row(p, bm + row);
+            const long ci = (long)mo * e.ldc + n;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                if (r < nv) {
-                    if (p.epi.C_pre) store_from_f32(p.epi.C_pre, ci + r, p.epi.c_dtype, pre[r]);
-                    float o = v[r];
-                    if (p.epi.accum) o += load_as_f32(p.epi.C, ci + r, p.epi.c_dtype);
-                    store_from_f32(p.epi.C, ci + r, p.epi.c_dtype, o);
+                v[r] = v[r] * e.alpha + b8[r];
+                pre[r] = v[r];
+            }
+            if (e.act == ATHENA_ACT_RELU6) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = relu6f(v[r]);
+            } else if (e.act == ATHENA_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+            } else if (e.act == ATHENA_ACT_MUL_DGELU || e.act == ATHENA_ACT_MUL_DRELU6) {
+                float a[8];
+                const long ai = (long)mo * e.ldaux + n;
+                if (aux_vec && e.aux_dtype == ATHENA_BF16) {
+                    const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)e.aux + ai);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) a[r] = (float)h[r];
+                } else if (aux_vec) {
+                    const float4 h0 = *(const float4*)((const float*)e.aux + ai);
+                    const float4 h1 = *(const float4*)((const float*)e.aux + ai + 4);
+                    a[0] = h0.x; a[1] = h0.y; a[2] = h0.z; a[3] = h0.w;
+                    a[4] = h1.x; a[5] = h1.y; a[6] = h1.z; a[7] = h1.w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) a[r] = r < nv ? load_as_f32(e.aux, ai + r, e.aux_dtype) : 0.f;
+                }
+                if (e.act == ATHENA_ACT_MUL_DGELU) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= dgelu_tanh_f(a[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = (a[r] > 0.f && a[r] < 6.f) ? v[r] : 0.f;
+                }
+            }
+            if (e.drop_thresh) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= dropout_mult(key, (uint64_t)(ci + r), e.drop_thresh, e.drop_scale);
+            }
+            if (e.colsum) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float sv = v[r];
+                    if (bf_out) sv = (float)(bf16_t)sv;
+                    if (r < nv) { csum[r] += sv; csq[r] += sv * sv; }
+                }
+            }
+            if (vec8) {
+                if (bf_out) {
+                    bf16_t* c = (bf16_t*)e.C + ci;
+                    if (e.C_pre) {
+                        bf16x8_t pv;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) pv[r] = (bf16_t)pre[r];
+                        *(bf16x8_t*)((bf16_t*)e.C_pre + ci) = pv;
+                    }
+                    if (e.accum) {
+                        const bf16x8_t old = *(const bf16x8_t*)c;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += (float)old[r];
+                    }
+                    bf16x8_t o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+                    *(bf16x8_t*)c = o;
+                } else {
+                    float* c = (float*)e.C + ci;
+                    if (e.C_pre) {
+                        float* cp = (float*)e.C_pre + ci;
+                        *(float4*)cp = make_float4(pre[0], pre[1], pre[2], pre[3]);
+                        *(float4*)(cp + 4) = make_float4(pre[4], pre[5], pre[6], pre[7]);
+                    }
+                    if (e.accum) {
+                        const float4 o0 = *(const float4*)c, o1 = *(const float4*)(c + 4);
+                        v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w;
+                        v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                    }
+                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < nv) {
+                        if (e.C_pre) store_from_f32(e.C_pre, ci + r, e.c_dtype, pre[r]);
+                        float o = v[r];
+                        if (e.accum) o += load_as_f32(e.C, ci + r, e.c_dtype);
+                        store_from_f32(e.C, ci + r, e.c_dtype, o);
+                    }
                 }
             }
         }
     }
-    if (p.epi.colsum) {
+    if (e.colsum) {
         // threads with equal (tid % CPR) own the same 8 columns: fold inside the wave, then across
         // the four waves through LDS, so a block issues one fp64 atomic per column and statistic
         __syncthreads();                              // every thread is done reading sC
@@ -574,7 +653,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmProblem<AMap> p) {
             const int col = tid >> 1, which = tid & 1;
             const float t = red[(0 * BT + col) * 2 + which] + red[(1 * BT + col) * 2 + which] +
                             red[(2 * BT + col) * 2 + which] + red[(3 * BT + col) * 2 + which];
-            if (bn + col < p.N) atomicAdd(p.epi.colsum + which * p.N + bn + col, (double)t);
+            if (bn + col < p.N) atomicAdd(e.colsum + which * p.N + bn + col, (double)t);
         }
     }
 }
