@@ -166,14 +166,15 @@ extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout,
     p.N = Cout;
     p.nseg = 9;
     p.kseg = Cin;
+    p.b_mask = 15;           // segment s = tap s, offsets linear in s
     p.seg_base = 0;
     p.split_k = 1;
     if (w_layout == 1) {   // [Cout][9][Cin]
         p.ldb = 9L * Cin;
-        for (int s = 0; s < 9; ++s) p.b_seg_off[s] = (long)s * Cin;
+        p.b_stride_lo = Cin;
     } else {               // HWIO [9][Cin][Cout]
         p.ldb = Cout;
-        for (int s = 0; s < 9; ++s) p.b_seg_off[s] = (long)s * Cin * Cout;
+        p.b_stride_lo = (long)Cin * Cout;
     }
     p.epi.C = out;
     p.epi.ldc = Cout;
@@ -216,14 +217,17 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
             p.A = dout;
             p.B = w_hwio;
             p.amap.Ho = Ho; p.amap.Wo = Wo; p.amap.Co = Cout; p.amap.Ah = Ah; p.amap.Aw = Aw;
-            int s = 0;
-            for (int i = 0; i < nh; ++i)
-                for (int j = 0; j < nw; ++j) {
-                    p.amap.dh[s] = dhs[i];
-                    p.amap.dw[s] = dws[j];
-                    p.b_seg_off[s] = (long)(khs[i] * 3 + kws[j]) * Cin * Cout;
-                    ++s;
-                }
+            // segment s = i * nw + j walks the taps (kh = khs[i], kw = kws[j]) of this class:
+            // i = s >> shift, j = s & mask; dh = a0h - i, dw = a0w - j; kh = 2i (or 1), kw = 2j (or 1)
+            const int s = nh * nw;
+            const int shift = nw == 2 ? 1 : 0, mask = nw == 2 ? 1 : 0;
+            p.amap.dh0 = a0h; p.amap.dw0 = a0w; p.amap.shift = shift; p.amap.mask = mask;
+            p.b_shift = shift;
+            p.b_mask = mask;
+            p.b_base = (long)(khs[0] * 3 + kws[0]) * Cin * Cout;
+            p.b_stride_hi = nh == 2 ? 6L * Cin * Cout : 0;
+            p.b_stride_lo = nw == 2 ? 2L * Cin * Cout : 0;
+            (void)dhs; (void)dws;
             p.M = B * Ah * Aw;
             p.N = Cin;
             p.nseg = s;

@@ -118,6 +118,7 @@ __device__ __forceinline__ void epilogue_store4(const Epilogue& e, int m, int n,
 // (or -1 when the row is all zeros there); step(row, d) moves to row r + d.
 struct PlainRows {
     static constexpr bool kCanMiss = false;    // off() never reports an all-zero row
+    static constexpr bool kSegmented = false;  // the contraction is one segment
     long ld;
     struct Row { long base; };
     __device__ __forceinline__ Row prep(int r) const { return Row{(long)r * ld}; }
@@ -130,6 +131,7 @@ struct PlainRows {
 // input pixel (2*ho - pad_h + kh, 2*wo - pad_w + kw), zero outside the image.
 struct ConvFwdRows {
     static constexpr bool kCanMiss = true;
+    static constexpr bool kSegmented = true;
     int H, W, C, Ho, Wo, pad_h, pad_w;
     struct Row { int b, ho, wo; };
     __device__ __forceinline__ Row prep(int r) const {
@@ -156,11 +158,12 @@ struct ConvFwdRows {
 // Rows for the input gradient of the same convolution, one launch per parity class of the
 // input pixel.  Row r = (b, ah, aw) <-> one input pixel of the class; segment s indexes the taps
 // that reach this class; the row is the Cout-vector of the output gradient at
-// (ah + dh[s], aw + dw[s]).
+// (ah + dh(s), aw + dw(s)), both affine in the two bit fields of s.
 struct ConvDgradRows {
     static constexpr bool kCanMiss = true;
+    static constexpr bool kSegmented = true;
     int Ho, Wo, Co, Ah, Aw;     // Ah x Aw = pixels of this class per image
-    int dh[4], dw[4];
+    int dh0, dw0, shift, mask;  // segment s reads the output pixel (ah + dh0 - (s >> shift), aw + dw0 - (s & mask))
     struct Row { int b, ah, aw; };
     __device__ __forceinline__ Row prep(int r) const {
         Row x;
@@ -171,7 +174,7 @@ struct ConvDgradRows {
         return x;
     }
     __device__ __forceinline__ long off(const Row& x, int seg) const {
-        const int ho = x.ah + dh[seg], wo = x.aw + dw[seg];
+        const int ho = x.ah + dh0 - (seg >> shift), wo = x.aw + dw0 - (seg & mask);
         if (ho < 0 || ho >= Ho || wo < 0 || wo >= Wo) return -1;
         return (((long)x.b * Ho + ho) * Wo + wo) * Co;
     }
@@ -191,7 +194,9 @@ struct GemmProblem {
     int M, N;
     int nseg, kseg;          // K = nseg * kseg
     long ldb;                // leading dimension of B
-    long b_seg_off[9];       // element offset of B for each segment
+    // element offset of B for segment s: b_base + (s >> b_shift) * b_stride_hi + (s & b_mask) * b_stride_lo
+    long b_base, b_stride_lo, b_stride_hi;
+    int b_shift, b_mask;
     int seg_base;            // segment index passed to the row map = seg_base + local segment
     int split_k;             // number of K splits; splits are over k-tiles
     int zbatch;              // independent problems in grid.z (grid.z = zbatch * split_k); batch z uses
@@ -201,6 +206,11 @@ struct GemmProblem {
     int crow_mode;           // 0: identity; 1: parity-class scatter
     int cr_Ah, cr_Aw, cr_H, cr_W, cr_h0, cr_w0;   // crow = ((b*H + 2*ah+h0)*W + 2*aw+w0)
 };
+
+template <class AMap>
+__device__ __forceinline__ long b_seg_off(const GemmProblem<AMap>& p, int seg) {
+    return p.b_base + (long)(seg >> p.b_shift) * p.b_stride_hi + (long)(seg & p.b_mask) * p.b_stride_lo;
+}
 
 template <class AMap>
 __device__ __forceinline__ int out_row(const GemmProblem<AMap>& p, int m) {
@@ -324,18 +334,30 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
     // into the other set, so a global load has two tile-times to arrive
     uint4 ra0[NCH], rb0[NCH], ra1[NCH], rb1[NCH];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    // column sums of B (bias gradient of a weight-gradient GEMM): the first row of workgroups adds
-    // up the B pieces it stages anyway; a thread keeps the same 8 columns in every piece
-    const bool want_bsum = !TB && p.epi.bsum != nullptr && blockIdx.x == 0;
-    float bs[8];
+    // column sums of B (bias gradient of a weight-gradient GEMM): in the first row of workgroups
+    // the waves with wm == 0 multiply their B fragments with an all-ones A fragment as well, which
+    // leaves sum_k B(k, n) in every column of one extra accumulator per 16 columns
+    const bool want_bsum = !TB && p.epi.bsum != nullptr && blockIdx.x == 0 && wm == 0;
+    f32x4_t bs[WT];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) bs[r] = 0.f;
+    for (int j = 0; j < WT; ++j) bs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ones[r] = (bf16_t)1.0f;
 
-    auto load_tile = [&](int t, uint4 (&ra)[NCH], uint4 (&rb)[NCH]) {
-        const bool live = t < t_end;
-        const int seg = live ? t / tiles_per_seg : 0;
-        const int k0 = (t - seg * tiles_per_seg) * GM_BK;
-        const long bseg = p.b_seg_off[seg];
+    // tiles are loaded strictly in order t_begin, t_begin + 1, ...; (segment, k offset) of the next
+    // tile to load are carried along in scalar registers instead of being re-derived by a division
+    int ld_t = t_begin;
+    int ld_seg = AMap::kSegmented ? t_begin / tiles_per_seg : 0;
+    int ld_k0 = (t_begin - ld_seg * tiles_per_seg) * GM_BK;
+    auto load_tile = [&](uint4 (&ra)[NCH], uint4 (&rb)[NCH]) {
+        const bool live = ld_t < t_end;
+        const int seg = live ? ld_seg : 0;
+        const int k0 = ld_k0;
+        const long bseg = AMap::kSegmented ? b_seg_off(p, seg) : p.b_base;
+        ++ld_t;
+        ld_k0 += GM_BK;
+        if (AMap::kSegmented && ld_k0 >= p.kseg) { ld_k0 = 0; ++ld_seg; }
         // Zero-filling is done by AND-ing the loaded words with a mask after an always-valid load
         // (a select between a load and zero would be turned into a load through a selected pointer
         // to a zero kept in scratch memory).
@@ -390,14 +412,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
             if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = rb[i];
             else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = rb[i];
         }
-        if (!TB && want_bsum) {
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const bf16x8_t h = __builtin_bit_cast(bf16x8_t, rb[i]);
-#pragma unroll
-                for (int r = 0; r < 8; ++r) bs[r] += (float)h[r];
-            }
-        }
     };
     auto multiply_tile = [&](int buf) {
         const bf16_t* sA = lds + buf * (A_ELEMS + B_ELEMS);
@@ -421,47 +435,71 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
 #pragma unroll
                 for (int j = 0; j < WT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (!TB && want_bsum) {
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    bs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ones, bs[j], 0, 0, 0);
+            }
         }
     };
 
+    // Large tiles with a transposed operand need too many address registers to also afford the
+    // second staging set (two workgroups per CU leave 256 registers per lane): they prefetch one
+    // tile ahead, everything else two.
+    constexpr bool PF2 = (WT == 2) || (!TA && TB);
     if (t_begin < t_end) {
-        // tiles are taken in pairs; a tile index past t_end loads as zeros and multiplies to nothing,
-        // which keeps the loop body free of exits (one accumulator set, fixed register roles)
-        load_tile(t_begin, ra0, rb0);
-        load_tile(t_begin + 1, ra1, rb1);
-        store_tile(0, ra0, rb0);
-        __syncthreads();
-#pragma nounroll
-        for (int t = t_begin; t < t_end; t += 2) {
-            // LDS stage 0 holds tile t, set 1 holds tile t+1
-            load_tile(t + 2, ra0, rb0);
-            multiply_tile(0);
-            store_tile(1, ra1, rb1);
-            __syncthreads();
-            // LDS stage 1 holds tile t+1, set 0 holds tile t+2
-            load_tile(t + 3, ra1, rb1);
-            multiply_tile(1);
+        if constexpr (PF2) {
+            // tiles are taken in pairs; a tile index past t_end loads as zeros and multiplies to
+            // nothing, which keeps the loop body free of exits (one accumulator set, fixed register roles)
+            load_tile(ra0, rb0);
+            load_tile(ra1, rb1);
             store_tile(0, ra0, rb0);
             __syncthreads();
-        }
-    }
-    if (!TB && want_bsum) {
-        float* red = (float*)lds;                 // [256 threads][8], 8 KB
-#pragma unroll
-        for (int r = 0; r < 8; ++r) red[tid * 8 + r] = bs[r];
-        __syncthreads();
-        if (tid < BT) {
-            // column tid of the tile = chunk tid / 8, element tid % 8; owners are threads == chunk (mod NC)
-            float t = 0.f;
-            for (int o = tid >> 3; o < 256; o += NC) t += red[o * 8 + (tid & 7)];
-            const int n = bn + tid;
-            if (n < p.N) {
-                if (p.epi.atomic == 2) p.epi.partial[((long)blockIdx.z * (p.M + 1) + p.M) * p.epi.ldp + n] = t;
-                else if (p.epi.atomic == 1) atomicAdd(p.epi.bsum + n, t);
-                else p.epi.bsum[n] = t;
+#pragma nounroll
+            for (int t = t_begin; t < t_end; t += 2) {
+                // LDS stage 0 holds tile t, set 1 holds tile t+1
+                load_tile(ra0, rb0);
+                multiply_tile(0);
+                store_tile(1, ra1, rb1);
+                __syncthreads();
+                // LDS stage 1 holds tile t+1, set 0 holds tile t+2
+                load_tile(ra1, rb1);
+                multiply_tile(1);
+                store_tile(0, ra0, rb0);
+                __syncthreads();
+            }
+        } else {
+            load_tile(ra0, rb0);
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+#pragma nounroll
+            for (int t = t_begin; t < t_end; t += 2) {
+                load_tile(ra0, rb0);
+                multiply_tile(0);
+                store_tile(1, ra0, rb0);
+                __syncthreads();
+                load_tile(ra0, rb0);
+                multiply_tile(1);
+                store_tile(0, ra0, rb0);
+                __syncthreads();
             }
         }
-        __syncthreads();
+    }
+    if (!TB && want_bsum && (lane & 15) == 0) {
+        // lane 16 g holds columns n0 + 4 g + r of each 16-column tile
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = bn + wn * 16 * WT + j * 16 + 4 * (lane >> 4) + r;
+                if (n < p.N) {
+                    const float t = bs[j][r];
+                    if (p.epi.atomic == 2) p.epi.partial[((long)blockIdx.z * (p.M + 1) + p.M) * p.epi.ldp + n] = t;
+                    else if (p.epi.atomic == 1) atomicAdd(p.epi.bsum + n, t);
+                    else p.epi.bsum[n] = t;
+                }
+            }
+        }
     }
 
     // epilogue.  Element r of acc[i][j] is C[m = m0 + (lane & 15)][n = n0 + 4*(lane >> 4) + r].  The
@@ -718,7 +756,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
                 const int n = bn + nn, k = k0 + kk;
                 float v = 0.f;
                 if (n < p.N && k < p.kseg) {
-                    const long base = p.b_seg_off[seg];
+                    const long base = b_seg_off(p, seg);
                     v = TB ? B[base + (long)n * p.ldb + k] : B[base + (long)k * p.ldb + n];
                 }
                 sB[kk][nn] = v;
