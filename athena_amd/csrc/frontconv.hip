@@ -1,0 +1,362 @@
+// First front-end layer, fused: Conv2D(3x3, stride 2, same, ONE input channel) -> BatchNormalization
+// (batch statistics) -> relu6, forward and backward
+// (reference athena/models/speech_transformer.py:72-93, the fbank input has one channel).
+//
+// With one input channel a pre-activation is x[p][c] = sum_t a[p][t] w[t][c] over the 9 taps
+// a[p][.] of the input around output pixel p, so everything BatchNormalization needs from the
+// [pixels x channels] tensor is a function of the 9 + 45 input moments
+//     S[t] = sum_p a[p][t],   R[t][u] = sum_p a[p][t] a[p][u]
+// and the 9 x C weights: the pre-activation tensor is never written.
+//   forward : moments -> per-channel sum / sum of squares (closed form, fp64) -> mean, rstd;
+//             one pass recomputes the 9 multiply-adds per element, applies BN + relu6 and stores y.
+//   backward: g = dL/d(BN output) comes in already gated by relu6 (the producer masks it with the
+//             stored y); one pass reduces T[t][c] = sum_p a[p][t] g[p][c] and sb[c] = sum_p g[p][c];
+//             dbeta = sb, dgamma = rstd (sum_t w T - mean sb), and
+//             dw[t][c] = gamma rstd ( T - sb/n S[t] - dgamma/n rstd (sum_u R[t][u] w[u][c] - mean S[t]) ).
+#include "common.h"
+
+#define FC_K 9                      // taps
+#define FC_NMOM (FC_K + FC_K * FC_K)
+
+static inline void fc_same_pad(int n, int* out, int* pad_before) {
+    int o = (n + 1) / 2;
+    int total = (o - 1) * 2 + 3 - n;
+    if (total < 0) total = 0;
+    *out = o;
+    *pad_before = total / 2;
+}
+
+// the 9 taps around output pixel (b, ho, wo); zero outside the image
+__device__ __forceinline__ void fc_taps(const float* __restrict__ in, int H, int W, int b, int ho, int wo, int ph,
+                                        int pw, float (&a)[FC_K]) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * ho - ph + kh;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int x = 2 * wo - pw + kw;
+            const bool ok = h >= 0 && h < H && x >= 0 && x < W;
+            const long o = ok ? ((long)b * H + h) * W + x : 0;
+            const float v = in[o];
+            a[kh * 3 + kw] = ok ? v : 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- input moments
+__global__ __launch_bounds__(256) void fc_moments_kernel(const float* __restrict__ in, int B, int H, int W, int Ho,
+                                                         int Wo, int ph, int pw, double* __restrict__ mom) {
+    __shared__ double red[4][FC_K + FC_K * (FC_K + 1) / 2];
+    const long npix = (long)B * Ho * Wo;
+    // fp64 throughout: the variance is a difference of these sums
+    double s[FC_K], r[FC_K * (FC_K + 1) / 2];
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) s[t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < FC_K * (FC_K + 1) / 2; ++t) r[t] = 0.0;
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+        const int wo = (int)(pix % Wo);
+        const long q = pix / Wo;
+        float a[FC_K];
+        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        int idx = 0;
+#pragma unroll
+        for (int t = 0; t < FC_K; ++t) {
+            s[t] += (double)a[t];
+#pragma unroll
+            for (int u = t; u < FC_K; ++u) { r[idx] = fma((double)a[t], (double)a[u], r[idx]); ++idx; }
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    auto wave_sum_f64 = [](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) {
+        const double v = wave_sum_f64(s[t]);
+        if (lane == 0) red[w][t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < FC_K * (FC_K + 1) / 2; ++t) {
+        const double v = wave_sum_f64(r[t]);
+        if (lane == 0) red[w][FC_K + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < FC_K + FC_K * (FC_K + 1) / 2) {
+        const int i = threadIdx.x;
+        const double v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (i < FC_K) {
+            atomicAdd(mom + i, v);
+        } else {
+            // triangular index -> (t, u), t <= u; the matrix is stored full
+            int k = i - FC_K, t = 0;
+            while (k >= FC_K - t) { k -= FC_K - t; ++t; }
+            const int u = t + k;
+            atomicAdd(mom + FC_K + t * FC_K + u, v);
+            if (u != t) atomicAdd(mom + FC_K + u * FC_K + t, v);
+        }
+    }
+}
+
+// per-channel sum and sum of squares of the pre-activations, from the moments
+__global__ void fc_colstats_kernel(const double* __restrict__ mom, const float* __restrict__ w, int C,
+                                   double* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double wc[FC_K];
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) wc[t] = (double)w[t * C + c];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) {
+        s1 += wc[t] * mom[t];
+        double row = 0.0;
+#pragma unroll
+        for (int u = 0; u < FC_K; ++u) row += wc[u] * mom[FC_K + t * FC_K + u];
+        s2 += wc[t] * row;
+    }
+    stats[c] = s1;
+    stats[C + c] = s2 < 0.0 ? 0.0 : s2;
+}
+
+extern "C" int athena_conv1_bn_stats(const float* in, const float* w_hwio, int B, int H, int W, int Cout,
+                                     double* moments, double* colstats, athena_stream_t stream) {
+    ATHENA_REQUIRE(in && w_hwio && moments && colstats && B > 0 && H > 0 && W > 0 && Cout > 0, ATHENA_E_SHAPE,
+                   "athena_conv1_bn_stats: bad arguments");
+    int Ho, Wo, ph, pw;
+    fc_same_pad(H, &Ho, &ph);
+    fc_same_pad(W, &Wo, &pw);
+    hipStream_t s = (hipStream_t)stream;
+    ATHENA_REQUIRE(hipMemsetAsync(moments, 0, sizeof(double) * FC_NMOM, s) == hipSuccess, ATHENA_E_LAUNCH,
+                   "athena_conv1_bn_stats: memset failed");
+    const long npix = (long)B * Ho * Wo;
+    long blocks = (npix + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(fc_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, Ho, Wo, ph, pw, moments);
+    hipLaunchKernelGGL(fc_colstats_kernel, dim3((Cout + 127) / 128), dim3(128), 0, s, (const double*)moments, w_hwio,
+                       Cout, colstats);
+    ATHENA_CHECK_LAUNCH("athena_conv1_bn_stats");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- forward: conv + BN + relu6 in one pass
+// thread = (pixel slot, 8 channels); its 72 weights and the BN scale/shift stay in registers
+template <typename T> __device__ __forceinline__ T fc_store_cast(float y);
+template <> __device__ __forceinline__ float fc_store_cast<float>(float y) { return y; }
+template <> __device__ __forceinline__ bf16_t fc_store_cast<bf16_t>(float y) {
+    // a value below 6 must not round up to 6: the backward pass reads the relu6 gate off the
+    // stored value, so it is kept at the largest bf16 below 6 instead
+    bf16_t r = (bf16_t)y;
+    if (y < 6.f && (float)r >= 6.f) r = __builtin_bit_cast(bf16_t, (unsigned short)0x40BF);
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ s0, const float* __restrict__ s1,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, int infer, int B, int H, int W, int C, int Ho, int Wo,
+                                                     int ph, int pw, T* __restrict__ out) {
+    const int cpr = C / 8;                           // 8-channel chunks per pixel; host guarantees 256 % cpr == 0
+    const int chunk = threadIdx.x % cpr, slot = threadIdx.x / cpr, slots = 256 / cpr;
+    const int c0 = chunk * 8;
+    float wr[FC_K][8], sc[8], sh[8];
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wr[t][i] = w[t * C + c0 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float mu = s0[c0 + i];
+        const float rs = infer ? rsqrtf(s1[c0 + i] + eps) : s0[C + c0 + i];
+        sc[i] = rs * gamma[c0 + i];
+        sh[i] = beta[c0 + i] - mu * sc[i];
+    }
+    const long npix = (long)B * Ho * Wo;
+    for (long pix = (long)blockIdx.x * slots + slot; pix < npix; pix += (long)gridDim.x * slots) {
+        const int wo = (int)(pix % Wo);
+        const long q = pix / Wo;
+        float a[FC_K];
+        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < FC_K; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(a[t], wr[t][i], acc[i]);
+        if (sizeof(T) == 2) {
+            bf16x8_t o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fc_store_cast<bf16_t>(relu6f(fmaf(acc[i], sc[i], sh[i])));
+            *(bf16x8_t*)((bf16_t*)out + pix * C + c0) = o;
+        } else {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = relu6f(fmaf(acc[i], sc[i], sh[i]));
+            float* op = (float*)out + pix * C + c0;
+            *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
+static int fc_check(const char* name, int B, int H, int W, int C, int dtype) {
+    ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, ATHENA_E_SHAPE, "%s: bad shape", name);
+    ATHENA_REQUIRE(C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, ATHENA_E_UNSUPPORTED,
+                   "%s: channel count %d must be 8 * a divisor of 256", name, C);
+    ATHENA_REQUIRE(dtype == ATHENA_F32 || dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "%s: dtype", name);
+    return ATHENA_OK;
+}
+
+extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, const float* s0, const float* s1,
+                                         const float* gamma, const float* beta, float eps, int infer, int B, int H,
+                                         int W, int Cout, int dtype, void* out, athena_stream_t stream) {
+    int rc = fc_check("athena_conv1_bn_relu6_fwd", B, H, W, Cout, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(in && w_hwio && s0 && gamma && beta && out && (!infer || s1), ATHENA_E_SHAPE,
+                   "athena_conv1_bn_relu6_fwd: null operand");
+    ATHENA_REQUIRE(athena_aligned16(out), ATHENA_E_ALIGN, "athena_conv1_bn_relu6_fwd: out must be 16-byte aligned");
+    int Ho, Wo, ph, pw;
+    fc_same_pad(H, &Ho, &ph);
+    fc_same_pad(W, &Wo, &pw);
+    const long npix = (long)B * Ho * Wo;
+    const int slots = 256 / (Cout / 8);
+    long blocks = (npix + slots - 1) / slots;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta,
+                           eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta,
+                           eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (float*)out);
+    ATHENA_CHECK_LAUNCH("athena_conv1_bn_relu6_fwd");
+    return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- backward
+#define FC_BWD_BLOCKS 512
+// partial[blk][t][c] (t < 9: sum a g; t == 9: sum g), fp32, one slab per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restrict__ in, const T* __restrict__ g,
+                                                            int B, int H, int W, int C, int Ho, int Wo, int ph, int pw,
+                                                            float* __restrict__ partial) {
+    extern __shared__ float red[];                   // [(FC_K + 1)][C]
+    const int cpr = C / 8;
+    const int chunk = threadIdx.x % cpr, slot = threadIdx.x / cpr, slots = 256 / cpr;
+    const int c0 = chunk * 8;
+    float acc[FC_K + 1][8];
+#pragma unroll
+    for (int t = 0; t <= FC_K; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+    for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const long npix = (long)B * Ho * Wo;
+    for (long pix = (long)blockIdx.x * slots + slot; pix < npix; pix += (long)gridDim.x * slots) {
+        const int wo = (int)(pix % Wo);
+        const long q = pix / Wo;
+        float a[FC_K], gv[8];
+        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        if (sizeof(T) == 2) {
+            const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + pix * C + c0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gv[i] = (float)h[i];
+        } else {
+            const float* gp = (const float*)g + pix * C + c0;
+            const float4 h0 = *(const float4*)gp, h1 = *(const float4*)(gp + 4);
+            gv[0] = h0.x; gv[1] = h0.y; gv[2] = h0.z; gv[3] = h0.w;
+            gv[4] = h1.x; gv[5] = h1.y; gv[6] = h1.z; gv[7] = h1.w;
+        }
+#pragma unroll
+        for (int t = 0; t < FC_K; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[t][i] = fmaf(a[t], gv[i], acc[t][i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[FC_K][i] += gv[i];
+    }
+    // fold the pixel slots of the workgroup in LDS, then store the slab
+#pragma unroll
+    for (int t = 0; t <= FC_K; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&red[t * C + c0 + i], acc[t][i]);
+    __syncthreads();
+    float* dst = partial + (long)blockIdx.x * (FC_K + 1) * C;
+    for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) dst[i] = red[i];
+}
+
+__global__ void fc_bwd_final_kernel(const float* __restrict__ partial, int nblk, const double* __restrict__ mom,
+                                    const float* __restrict__ w, const float* __restrict__ mean_rstd,
+                                    const float* __restrict__ gamma, long npix, int C, float* __restrict__ dw,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double T[FC_K + 1];
+#pragma unroll
+    for (int t = 0; t <= FC_K; ++t) T[t] = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* src = partial + (long)b * (FC_K + 1) * C + c;
+#pragma unroll
+        for (int t = 0; t <= FC_K; ++t) T[t] += (double)src[t * C];
+    }
+    const double sb = T[FC_K];
+    const double mu = (double)mean_rstd[c], rs = (double)mean_rstd[C + c], ga = (double)gamma[c];
+    const double n = (double)npix;
+    double wc[FC_K];
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) wc[t] = (double)w[t * C + c];
+    double gx = 0.0;                                  // sum_p g x
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) gx += wc[t] * T[t];
+    const double sg = rs * (gx - mu * sb);            // sum_p g xhat
+    dbeta[c] = (float)sb;
+    dgamma[c] = (float)sg;
+#pragma unroll
+    for (int t = 0; t < FC_K; ++t) {
+        double rw = 0.0;                              // sum_p a[p][t] x[p][c]
+#pragma unroll
+        for (int u = 0; u < FC_K; ++u) rw += mom[FC_K + t * FC_K + u] * wc[u];
+        const double axh = rs * (rw - mu * mom[t]);   // sum_p a[p][t] xhat[p][c]
+        dw[t * C + c] = (float)(ga * rs * (T[t] - sb / n * mom[t] - sg / n * axh));
+    }
+}
+
+extern "C" int64_t athena_conv1_bn_bwd_workspace_bytes(int Cout) {
+    return (int64_t)sizeof(float) * FC_BWD_BLOCKS * (FC_K + 1) * (Cout > 0 ? Cout : 0);
+}
+
+extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const float* w_hwio, const double* moments,
+                                   const float* mean_rstd, const float* gamma, int B, int H, int W, int Cout,
+                                   int dtype, void* workspace, int64_t workspace_bytes, float* dw_hwio, float* dgamma,
+                                   float* dbeta, athena_stream_t stream) {
+    int rc = fc_check("athena_conv1_bn_bwd", B, H, W, Cout, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(in && g && w_hwio && moments && mean_rstd && gamma && workspace && dw_hwio && dgamma && dbeta,
+                   ATHENA_E_SHAPE, "athena_conv1_bn_bwd: null operand");
+    ATHENA_REQUIRE(athena_aligned16(g) && athena_aligned16(workspace), ATHENA_E_ALIGN,
+                   "athena_conv1_bn_bwd: g and workspace must be 16-byte aligned");
+    ATHENA_REQUIRE(workspace_bytes >= athena_conv1_bn_bwd_workspace_bytes(Cout), ATHENA_E_SHAPE,
+                   "athena_conv1_bn_bwd: workspace too small (%lld bytes)", (long long)workspace_bytes);
+    int Ho, Wo, ph, pw;
+    fc_same_pad(H, &Ho, &ph);
+    fc_same_pad(W, &Wo, &pw);
+    const long npix = (long)B * Ho * Wo;
+    const int slots = 256 / (Cout / 8);
+    long blocks = (npix + slots - 1) / slots;
+    if (blocks > FC_BWD_BLOCKS) blocks = FC_BWD_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t shm = sizeof(float) * (FC_K + 1) * Cout;
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(fc_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const bf16_t*)g, B,
+                           H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
+    else
+        hipLaunchKernelGGL(fc_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const float*)g, B, H,
+                           W, Cout, Ho, Wo, ph, pw, (float*)workspace);
+    hipLaunchKernelGGL(fc_bwd_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, (const float*)workspace, (int)blocks,
+                       moments, w_hwio, mean_rstd, gamma, npix, Cout, dw_hwio, dgamma, dbeta);
+    ATHENA_CHECK_LAUNCH("athena_conv1_bn_bwd");
+    return ATHENA_OK;
+}

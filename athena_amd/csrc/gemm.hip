@@ -190,7 +190,7 @@ extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout,
 }
 
 extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void* din, int B, int H, int W, int Cin,
-                                      int Cout, int dtype, athena_stream_t stream) {
+                                      int Cout, int dtype, const void* relu6_out, athena_stream_t stream) {
     int rc = conv_check("athena_conv3x3s2_dgrad", B, H, W, Cin, Cout, dtype);
     if (rc) return rc;
     ATHENA_REQUIRE(dout && w_hwio && din, ATHENA_E_SHAPE, "athena_conv3x3s2_dgrad: null operand");
@@ -239,6 +239,13 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
             p.epi.ldc = Cin;
             p.epi.c_dtype = dtype;
             p.epi.alpha = 1.f;
+            if (relu6_out) {
+                // the input of this convolution is a relu6 output: mask the gradient with its gate
+                p.epi.act = ATHENA_ACT_MUL_DRELU6;
+                p.epi.aux = relu6_out;
+                p.epi.ldaux = Cin;
+                p.epi.aux_dtype = dtype;
+            }
             p.crow_mode = 1;
             p.cr_Ah = Ah; p.cr_Aw = Aw; p.cr_H = H; p.cr_W = W; p.cr_h0 = h0; p.cr_w0 = w0;
             rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,

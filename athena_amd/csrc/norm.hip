@@ -1,6 +1,7 @@
 // LayerNormalization (with fused residual add + dropout), BatchNormalization + relu6,
 // column sums.  All arithmetic in fp32 (fp64 for the batch statistics).
 #include "common.h"
+#include <initializer_list>
 
 // ---------------------------------------------------------------- 8-wide vector access
 template <typename T> struct Vec8;
@@ -152,6 +153,170 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restr
     for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dbeta + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
+
+// ---------------------------------------------------------------- vector kernels (d % 8 == 0, d <= 512)
+// A row is spread over a group of G lanes (G = power of two >= d / 8), one 16-byte piece of 8
+// elements per lane, so a row is read and written exactly once with full-width accesses and all
+// statistics are reduced with lane shuffles inside the group.
+__device__ __forceinline__ float group_sum(float v, int G) {
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps,
+                                                                    int rows, int d, int G, uint32_t thresh,
+                                                                    float dscale, const uint64_t* rng_state,
+                                                                    uint32_t site, T* __restrict__ z,
+                                                                    T* __restrict__ y, float* __restrict__ mean,
+                                                                    float* __restrict__ rstd) {
+    const int rpb = 256 / G;                         // rows per block
+    const int gl = threadIdx.x % G;
+    const int row = blockIdx.x * rpb + threadIdx.x / G;
+    const bool live = row < rows && gl * 8 < d;
+    const long base = (long)(row < rows ? row : rows - 1) * d + (gl * 8 < d ? gl * 8 : 0);
+    float v[8];
+    Vec8<T>::load(a + base, v);
+    if (b) {
+        float bv[8];
+        Vec8<T>::load(b + base, bv);
+        if (thresh) {
+            const uint64_t key = rng_key(rng_state, site);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bv[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bv[i];
+    }
+    // the stored z is what the backward pass reads; round-trip it so both passes see one value
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = live ? to_f32<T>(from_f32<T>(v[i])) : 0.f;
+        s += v[i];
+    }
+    if (live) Vec8<T>::store(z + base, v);
+    const float mu = group_sum(s, G) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float dv = live ? v[i] - mu : 0.f;
+        q += dv * dv;
+    }
+    const float rs = rsqrtf(group_sum(q, G) / d + eps);
+    if (live) {
+        float gm[8], bt[8], o[8];
+        Vec8<float>::load(gamma + gl * 8, gm);
+        Vec8<float>::load(beta + gl * 8, bt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (v[i] - mu) * rs * gm[i] + bt[i];
+        Vec8<T>::store(y + base, o);
+        if (gl == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+#define LNV_ROWS_PER_BLOCK 32
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ z,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma, int rows, int d,
+                                                                    int G, uint32_t thresh, float dscale,
+                                                                    const uint64_t* rng_state, uint32_t site,
+                                                                    int accumulate_da, T* __restrict__ da,
+                                                                    T* __restrict__ db, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta) {
+    __shared__ float red[2][512];
+    const int rpp = 256 / G;                         // rows per pass of the block
+    const int gl = threadIdx.x % G, gi = threadIdx.x / G;
+    const bool col_ok = gl * 8 < d;
+    const int c0 = col_ok ? gl * 8 : 0;
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    float g[8], pg[8], pb[8];
+    Vec8<float>::load(gamma + c0, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * LNV_ROWS_PER_BLOCK;
+    const int r1 = min(rows, r0 + LNV_ROWS_PER_BLOCK);
+    for (int rb = r0; rb < r1; rb += rpp) {
+        const int row = rb + gi;
+        const bool live = row < r1 && col_ok;
+        const int rc = row < r1 ? row : r1 - 1;
+        const long base = (long)rc * d + c0;
+        const float mu = mean[rc], rs = rstd[rc];
+        float dyv[8], x[8], gy[8];
+        Vec8<T>::load(dy + base, dyv);
+        Vec8<T>::load(z + base, x);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dyv[i] = live ? dyv[i] : 0.f;
+            x[i] = live ? (x[i] - mu) * rs : 0.f;
+            gy[i] = dyv[i] * g[i];
+            pg[i] += dyv[i] * x[i];
+            pb[i] += dyv[i];
+            c1 += gy[i];
+            c2 += gy[i] * x[i];
+        }
+        c1 = group_sum(c1, G) / d;
+        c2 = group_sum(c2, G) / d;
+        if (live) {
+            float dz[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dz[i] = rs * (gy[i] - c1 - x[i] * c2);
+            if (accumulate_da) {
+                float old[8];
+                Vec8<T>::load(da + base, old);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) old[i] += dz[i];
+                Vec8<T>::store(da + base, old);
+            } else {
+                Vec8<T>::store(da + base, dz);
+            }
+            if (db) {
+                if (thresh) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dz[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+                }
+                Vec8<T>::store(db + base, dz);
+            }
+        }
+    }
+    // fold the row groups of the block in LDS, then one atomic per column per block
+    if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&red[0][c0 + i], pg[i]);
+            atomicAdd(&red[1][c0 + i], pb[i]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(dgamma + c, red[0][c]);
+        atomicAdd(dbeta + c, red[1][c]);
+    }
+}
+
+static inline int ln_group(int d) {
+    int G = 1;
+    while (G * 8 < d) G <<= 1;
+    return G;
+}
+static inline bool ln_vec_ok(int d, std::initializer_list<const void*> ptrs) {
+    if (d % 8 || d > 512) return false;
+    for (const void* p : ptrs)
+        if (p && !athena_aligned16(p)) return false;
+    return true;
+}
+
 extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta,
                                         float eps, int rows, int d, int dtype, float drop_p,
                                         const uint64_t* rng_state, uint32_t rng_site, void* z, void* y,
@@ -161,6 +326,20 @@ extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const floa
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && b), ATHENA_E_SHAPE, "add_layernorm_fwd: dropout args");
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    if ((dtype == ATHENA_BF16 || dtype == ATHENA_F32) && ln_vec_ok(d, {a, b, gamma, beta, z, y})) {
+        const int G = ln_group(d);
+        dim3 vgrid((rows + 256 / G - 1) / (256 / G));
+        if (dtype == ATHENA_BF16)
+            hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<bf16_t>, vgrid, dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)a, (const bf16_t*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
+                               rng_site, (bf16_t*)z, (bf16_t*)y, mean, rstd);
+        else
+            hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<float>, vgrid, dim3(256), 0, (hipStream_t)stream,
+                               (const float*)a, (const float*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
+                               rng_site, (float*)z, (float*)y, mean, rstd);
+        ATHENA_CHECK_LAUNCH("add_layernorm_fwd");
+        return ATHENA_OK;
+    }
     dim3 grid((rows + 3) / 4);
     if (dtype == ATHENA_BF16)
         hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
@@ -180,6 +359,13 @@ template <typename T>
 static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                          int rows, int d, uint32_t th, float ds, const uint64_t* rng_state, uint32_t site,
                          int acc, void* da, void* db, float* dgamma, float* dbeta, hipStream_t stream) {
+    if (ln_vec_ok(d, {dy, z, gamma, da, db})) {
+        dim3 vgrid((rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK);
+        hipLaunchKernelGGL((add_layernorm_bwd_vec_kernel<T>), vgrid, dim3(256), 0, stream, (const T*)dy, (const T*)z, mean,
+                           rstd, gamma, rows, d, ln_group(d), th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, dbeta);
+        ATHENA_CHECK_LAUNCH("add_layernorm_bwd");
+        return ATHENA_OK;
+    }
     dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK);
 #define LN_BWD_CASE(V)                                                                                          \
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, V>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)z, \
@@ -203,9 +389,14 @@ extern "C" int athena_add_layernorm_bwd(const void* dy, const void* z, const flo
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     hipStream_t s = (hipStream_t)stream;
-    ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, s) == hipSuccess &&
-                       hipMemsetAsync(dbeta, 0, sizeof(float) * d, s) == hipSuccess,
-                   ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
+    if (dbeta == dgamma + d) {       // adjacent (the usual parameter layout): one fill
+        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * d, s) == hipSuccess, ATHENA_E_LAUNCH,
+                       "add_layernorm_bwd: memset failed");
+    } else {
+        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, s) == hipSuccess &&
+                           hipMemsetAsync(dbeta, 0, sizeof(float) * d, s) == hipSuccess,
+                       ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
+    }
     if (dtype == ATHENA_BF16)
         return launch_ln_bwd<bf16_t>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, s);
     if (dtype == ATHENA_F32)

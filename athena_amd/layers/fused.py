@@ -294,18 +294,35 @@ class XNetFn(torch.autograd.Function):
         p = net.rate if training else 0.0
         x0 = x0.contiguous()
         stats = torch.empty(2 * C, dtype=torch.float64, device=dev) if training else None
-        # conv1 (few input channels: direct kernel on the fp32 input)
-        c1 = torch.empty((rows1, C), dtype=cd, device=dev)
-        ops.conv_small_cin_fwd(x0, net.conv1.kernel, c1, B, T, Fd, nc, C, stats)
-        a1 = torch.empty_like(c1)
-        mr1 = mr2 = None
-        if training:
-            mr1 = torch.empty(2 * C, dtype=torch.float32, device=dev)
-            ops.bn_finalize(stats, rows1, C, BN_EPS, BN_MOMENTUM, mr1, net.bn1.moving_mean, net.bn1.moving_variance)
-            ops.bn_relu6_apply(c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, a1)
+        mr1 = mr2 = mom1 = c1 = None
+        a1 = torch.empty((rows1, C), dtype=cd, device=dev)
+        fused1 = nc == 1 and C % 8 == 0 and 256 % (C // 8) == 0
+        if fused1:
+            # one input channel: conv + BN + relu6 in one pass, statistics in closed form from the
+            # input moments; the pre-activation tensor is never stored
+            if training:
+                mom1 = torch.empty(ops.CONV1_MOMENTS, dtype=torch.float64, device=dev)
+                mr1 = torch.empty(2 * C, dtype=torch.float32, device=dev)
+                ops.conv1_bn_stats(x0, net.conv1.kernel, B, T, Fd, C, mom1, stats)
+                ops.bn_finalize(stats, rows1, C, BN_EPS, BN_MOMENTUM, mr1, net.bn1.moving_mean,
+                                net.bn1.moving_variance)
+                ops.conv1_bn_relu6_fwd(x0, net.conv1.kernel, mr1, None, net.bn1.gamma, net.bn1.beta, BN_EPS, False, B,
+                                       T, Fd, C, a1)
+            else:
+                ops.conv1_bn_relu6_fwd(x0, net.conv1.kernel, net.bn1.moving_mean, net.bn1.moving_variance,
+                                       net.bn1.gamma, net.bn1.beta, BN_EPS, True, B, T, Fd, C, a1)
         else:
-            ops.bn_relu6_infer(c1, net.bn1.moving_mean, net.bn1.moving_variance, net.bn1.gamma, net.bn1.beta,
-                               BN_EPS, rows1, C, a1)
+            # a few input channels: direct kernel on the fp32 input, then BN + relu6
+            c1 = torch.empty((rows1, C), dtype=cd, device=dev)
+            ops.conv_small_cin_fwd(x0, net.conv1.kernel, c1, B, T, Fd, nc, C, stats)
+            if training:
+                mr1 = torch.empty(2 * C, dtype=torch.float32, device=dev)
+                ops.bn_finalize(stats, rows1, C, BN_EPS, BN_MOMENTUM, mr1, net.bn1.moving_mean,
+                                net.bn1.moving_variance)
+                ops.bn_relu6_apply(c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, a1)
+            else:
+                ops.bn_relu6_infer(c1, net.bn1.moving_mean, net.bn1.moving_variance, net.bn1.gamma, net.bn1.beta,
+                                   BN_EPS, rows1, C, a1)
         # conv2 (implicit GEMM)
         c2 = torch.empty((rows2, C), dtype=cd, device=dev)
         if cd == torch.bfloat16:
@@ -326,7 +343,7 @@ class XNetFn(torch.autograd.Function):
         out = torch.empty_like(y)
         ops.add_pe_dropout(y, st.pe(d), B, T2, d, 1.0, p, st.rng_state, net.site_drop, out)
         ctx.net, ctx.p, ctx.dims = net, p, (B, T, Fd, nc, C, d, T1, F1, T2, F2)
-        ctx.saved = (x0, c1, a1, mr1, c2, a2, mr2, y) if training else None
+        ctx.saved = (x0, c1, a1, mr1, mom1, c2, a2, mr2, y) if training else None
         return out.view(B, T2, d)
 
     @staticmethod
@@ -336,7 +353,7 @@ class XNetFn(torch.autograd.Function):
         net, p = ctx.net, ctx.p
         st = net.store
         B, T, Fd, nc, C, d, T1, F1, T2, F2 = ctx.dims
-        x0, c1, a1, mr1, c2, a2, mr2, y = ctx.saved
+        x0, c1, a1, mr1, mom1, c2, a2, mr2, y = ctx.saved
         ctx.saved = None
         dev = dout.device
         rows1, rows2 = B * T1 * F1, B * T2 * F2
@@ -354,11 +371,18 @@ class XNetFn(torch.autograd.Function):
         ops.conv3x3s2_wgrad(a1, dc2, net.conv2.kernel.grad, B, T1, F1, C, C)
         da1 = torch.empty_like(a1)
         w_hwio = net.conv2.shadow if c2.dtype == torch.bfloat16 else net.conv2.kernel
-        ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
-        dc1 = torch.empty_like(c1)
-        ops.bn_relu6_bwd(da1, c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, scratch, dc1, net.bn1.gamma.grad,
-                         net.bn1.beta.grad)
-        ops.conv_small_cin_wgrad(x0, dc1, net.conv1.kernel.grad, B, T, Fd, nc, C)
+        if mom1 is not None:
+            # da1 comes out already masked by the relu6 gate read off a1; the weight, gamma and beta
+            # gradients of the fused first layer need only its tap sums
+            ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C, relu6_out=a1)
+            ops.conv1_bn_bwd(x0, da1, net.conv1.kernel, mom1, mr1, net.bn1.gamma, B, T, Fd, C, net.conv1.kernel.grad,
+                             net.bn1.gamma.grad, net.bn1.beta.grad)
+        else:
+            ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
+            dc1 = torch.empty_like(c1)
+            ops.bn_relu6_bwd(da1, c1, mr1, net.bn1.gamma, net.bn1.beta, rows1, C, scratch, dc1, net.bn1.gamma.grad,
+                             net.bn1.beta.grad)
+            ops.conv_small_cin_wgrad(x0, dc1, net.conv1.kernel.grad, B, T, Fd, nc, C)
         return (None, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 

@@ -193,13 +193,15 @@ def conv3x3s2_fwd(x, w, w_layout, out, B, H, W, Cin, Cout, colstats):
                                         _ptr(colstats), _stream()), "athena_conv3x3s2_fwd")
 
 
-def conv3x3s2_dgrad(dout, w_hwio, din, B, H, W, Cin, Cout):
+def conv3x3s2_dgrad(dout, w_hwio, din, B, H, W, Cin, Cout, relu6_out=None):
     lib = _lib.load()
+    if relu6_out is not None and (relu6_out.numel() != din.numel() or relu6_out.dtype != din.dtype):
+        raise RuntimeError("athena_amd.conv3x3s2_dgrad: relu6_out must match din")
     if din.numel() != B * H * W * Cin or dout.numel() != B * same_out(H) * same_out(W) * Cout or \
             w_hwio.numel() < 9 * Cin * Cout or dout.dtype != w_hwio.dtype or din.dtype != dout.dtype:
         raise RuntimeError("athena_amd.conv3x3s2_dgrad: bad operands")
     _lib.check(lib.athena_conv3x3s2_dgrad(_ptr(dout), _ptr(w_hwio), _ptr(din), B, H, W, Cin, Cout, dt(dout),
-                                          _stream()), "athena_conv3x3s2_dgrad")
+                                          _ptr(relu6_out), _stream()), "athena_conv3x3s2_dgrad")
 
 
 def conv3x3s2_wgrad(x, dout, dw, B, H, W, Cin, Cout):
@@ -210,6 +212,43 @@ def conv3x3s2_wgrad(x, dout, dw, B, H, W, Cin, Cout):
     ws = splitk_workspace(x.device)
     _lib.check(lib.athena_conv3x3s2_wgrad(_ptr(x), _ptr(dout), _ptr(dw), B, H, W, Cin, Cout, dt(x), ws.data_ptr(),
                                           ws.numel(), _stream()), "athena_conv3x3s2_wgrad")
+
+
+CONV1_MOMENTS = 90
+
+
+def conv1_bn_stats(x, w_hwio, B, H, W, Cout, moments, colstats):
+    """Input moments and closed-form pre-activation statistics of the one-channel first layer."""
+    lib = _lib.load()
+    if x.dtype != torch.float32 or w_hwio.dtype != torch.float32 or x.numel() != B * H * W or \
+            w_hwio.numel() != 9 * Cout or moments.dtype != torch.float64 or moments.numel() < CONV1_MOMENTS or \
+            colstats.dtype != torch.float64 or colstats.numel() < 2 * Cout:
+        raise RuntimeError("athena_amd.conv1_bn_stats: bad operands")
+    _lib.check(lib.athena_conv1_bn_stats(_ptr(x), _ptr(w_hwio), B, H, W, Cout, _ptr(moments), _ptr(colstats),
+                                         _stream()), "athena_conv1_bn_stats")
+
+
+def conv1_bn_relu6_fwd(x, w_hwio, s0, s1, gamma, beta, eps, infer, B, H, W, Cout, out):
+    lib = _lib.load()
+    if x.dtype != torch.float32 or w_hwio.dtype != torch.float32 or x.numel() != B * H * W or \
+            w_hwio.numel() != 9 * Cout or out.numel() != B * same_out(H) * same_out(W) * Cout or \
+            s0.numel() < (Cout if infer else 2 * Cout):
+        raise RuntimeError("athena_amd.conv1_bn_relu6_fwd: bad operands")
+    _lib.check(lib.athena_conv1_bn_relu6_fwd(_ptr(x), _ptr(w_hwio), _ptr(s0), _ptr(s1), _ptr(gamma), _ptr(beta), eps,
+                                             int(infer), B, H, W, Cout, dt(out), _ptr(out), _stream()),
+               "athena_conv1_bn_relu6_fwd")
+
+
+def conv1_bn_bwd(x, g, w_hwio, moments, mean_rstd, gamma, B, H, W, Cout, dw, dgamma, dbeta):
+    lib = _lib.load()
+    if x.dtype != torch.float32 or x.numel() != B * H * W or g.numel() != B * same_out(H) * same_out(W) * Cout or \
+            dw.numel() != 9 * Cout or dw.dtype != torch.float32 or moments.numel() < CONV1_MOMENTS or \
+            mean_rstd.numel() < 2 * Cout or dgamma.numel() < Cout or dbeta.numel() < Cout:
+        raise RuntimeError("athena_amd.conv1_bn_bwd: bad operands")
+    ws = splitk_workspace(x.device)
+    _lib.check(lib.athena_conv1_bn_bwd(_ptr(x), _ptr(g), _ptr(w_hwio), _ptr(moments), _ptr(mean_rstd), _ptr(gamma), B,
+                                       H, W, Cout, dt(g), ws.data_ptr(), ws.numel(), _ptr(dw), _ptr(dgamma),
+                                       _ptr(dbeta), _stream()), "athena_conv1_bn_bwd")
 
 
 def conv_small_cin_fwd(x, w_hwio, out, B, H, W, Cin, Cout, colstats):

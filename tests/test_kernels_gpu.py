@@ -266,6 +266,60 @@ def test_mha_fully_masked_row_is_uniform_bf16(ops):
     assert bool(torch.isfinite(out.float()).all())
 
 
+@pytest.mark.parametrize("cd", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 13, 10, 32), (3, 40, 16, 64), (1, 7, 5, 8), (2, 50, 21, 256)])
+def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
+    """One-channel Conv2D -> BatchNorm (batch statistics) -> relu6 without the pre-activation tensor,
+    forward and the three parameter gradients, against autograd on the unfused fp64 chain."""
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, H, W, 1, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    w = (torch.randn(3, 3, 1, C, generator=g, dtype=torch.float64) * 0.8).float().double().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).float().double().requires_grad_(True)
+    beta = (torch.randn(C, generator=g, dtype=torch.float64) * 2 + 2).float().double().requires_grad_(True)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = x.float().double()
+    pre = om.conv2d_same_s2(x, w)
+    mean = pre.mean((0, 1, 2))
+    var = pre.var((0, 1, 2), unbiased=False)
+    y_ref = om.relu6((pre - mean) / torch.sqrt(var + 1e-3) * gamma + beta)
+    dy = torch.randn(B, Ho, Wo, C, generator=g, dtype=torch.float64)
+    xd, wd = x.float().to(dev()), w.detach().float().to(dev())
+    gd, bd = gamma.detach().float().to(dev()), beta.detach().float().to(dev())
+    mom = torch.empty(ops.CONV1_MOMENTS, dtype=torch.float64, device=dev())
+    stats = torch.empty(2 * C, dtype=torch.float64, device=dev())
+    ops.conv1_bn_stats(xd, wd, B, H, W, C, mom, stats)
+    n = B * Ho * Wo
+    assert_close(stats[:C], pre.detach().reshape(-1, C).sum(0), 1e-9, "sum of pre-activations")
+    assert_close(stats[C:], (pre.detach() ** 2).reshape(-1, C).sum(0), 1e-9, "sum of squares")
+    mr = torch.empty(2 * C, dtype=torch.float32, device=dev())
+    ops.bn_finalize(stats, n, C, 1e-3, 0.99, mr, None, None)
+    out = torch.full((B, Ho, Wo, C), float("nan"), dtype=cd, device=dev())
+    ops.conv1_bn_relu6_fwd(xd, wd, mr, None, gd, bd, 1e-3, False, B, H, W, C, out)
+    assert_close(out, y_ref.detach(), 1e-5 if cd == torch.float32 else 8e-3, "fused forward")
+    # the stored activation carries the exact gate
+    gate_ref = ((y_ref > 0) & (y_ref < 6)).detach()
+    o64 = out.double().cpu()
+    near = ((y_ref.detach() - 6).abs() < 1e-4) | (y_ref.detach().abs() < 1e-4)      # fp32 vs fp64 ties
+    assert bool((((o64 > 0) & (o64 < 6)) == gate_ref)[~near].all())
+    # backward: the producer hands over the gated gradient
+    gated = rounded(dy, cd) * gate_ref.double()
+    (y_ref * rounded(dy, cd)).sum().backward()
+    dw = torch.full((3, 3, 1, C), float("nan"), dtype=torch.float32, device=dev())
+    dg = torch.full((C,), float("nan"), dtype=torch.float32, device=dev())
+    db = torch.full((C,), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv1_bn_bwd(xd, to_cd(gated, cd), wd, mom, mr, gd, B, H, W, C, dw, dg, db)
+    assert_close(db, beta.grad, 2e-5, "dbeta")
+    assert_close(dg, gamma.grad, 5e-5, "dgamma")
+    assert_close(dw, w.grad, 5e-5, "dw")
+    # inference form: moving statistics
+    mm = (torch.randn(C, generator=g) * 0.1).to(dev())
+    mv = (torch.rand(C, generator=g) + 0.5).to(dev())
+    ops.conv1_bn_relu6_fwd(xd, wd, mm, mv, gd, bd, 1e-3, True, B, H, W, C, out)
+    y_inf = om.relu6((pre.detach() - mm.double().cpu()) / torch.sqrt(mv.double().cpu() + 1e-3) * gamma.detach() +
+                     beta.detach())
+    assert_close(out, y_inf, 1e-5 if cd == torch.float32 else 8e-3, "fused inference forward")
+
+
 # ------------------------------------------------------------------------------------------ conv / BN
 @pytest.mark.parametrize("cd", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 12, 10, 16, 24), (1, 13, 7, 8, 16), (3, 20, 9, 32, 136),
@@ -294,6 +348,10 @@ def test_conv3x3s2(ops, cd, B, H, W, Cin, Cout):
     din = torch.full((B, H, W, Cin), float("nan"), dtype=cd, device=dev())
     ops.conv3x3s2_dgrad(dyd, w_hwio, din, B, H, W, Cin, Cout)
     assert_close(din, xr.grad, tol, "conv dgrad")
+    # the same with the relu6 gate of the producing layer folded into the epilogue
+    act = rounded(om.relu6(torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64) * 4 + 2), cd)
+    ops.conv3x3s2_dgrad(dyd, w_hwio, din, B, H, W, Cin, Cout, relu6_out=to_cd(act, cd))
+    assert_close(din, xr.grad * ((act > 0) & (act < 6)).double(), tol, "conv dgrad with relu6 gate")
     dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=dev())
     ops.conv3x3s2_wgrad(xd, dyd, dw, B, H, W, Cin, Cout)
     assert_close(dw, wr.grad, tol, "conv wgrad")
