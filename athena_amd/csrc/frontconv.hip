@@ -36,7 +36,7 @@ __device__ __forceinline__ void fc_taps(const float* __restrict__ in, int H, int
         for (int kw = 0; kw < 3; ++kw) {
             const int x = 2 * wo - pw + kw;
             const bool ok = h >= 0 && h < H && x >= 0 && x < W;
-            const long o = ok ? ((long)b * H + h) * W + x : 0;
+            const int o = ok ? (b * H + h) * W + x : 0;        // < 2^31 elements (checked on the host)
             const float v = in[o];
             a[kh * 3 + kw] = ok ? v : 0.f;
         }
@@ -54,11 +54,11 @@ __global__ __launch_bounds__(256) void fc_moments_kernel(const float* __restrict
     for (int t = 0; t < FC_K; ++t) s[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < FC_K * (FC_K + 1) / 2; ++t) r[t] = 0.0;
-    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
-        const int wo = (int)(pix % Wo);
-        const long q = pix / Wo;
+    for (int pix = blockIdx.x * 256 + threadIdx.x; pix < (int)npix; pix += gridDim.x * 256) {
+        const int q = pix / Wo, wo = pix - q * Wo;
+        const int b = q / Ho, ho = q - b * Ho;
         float a[FC_K];
-        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        fc_taps(in, H, W, b, ho, wo, ph, pw, a);
         int idx = 0;
 #pragma unroll
         for (int t = 0; t < FC_K; ++t) {
@@ -123,8 +123,9 @@ __global__ void fc_colstats_kernel(const double* __restrict__ mom, const float* 
 
 extern "C" int athena_conv1_bn_stats(const float* in, const float* w_hwio, int B, int H, int W, int Cout,
                                      double* moments, double* colstats, athena_stream_t stream) {
-    ATHENA_REQUIRE(in && w_hwio && moments && colstats && B > 0 && H > 0 && W > 0 && Cout > 0, ATHENA_E_SHAPE,
-                   "athena_conv1_bn_stats: bad arguments");
+    ATHENA_REQUIRE(in && w_hwio && moments && colstats && B > 0 && H > 0 && W > 0 && Cout > 0 &&
+                       (long)B * H * W < (1L << 31),
+                   ATHENA_E_SHAPE, "athena_conv1_bn_stats: bad arguments");
     int Ho, Wo, ph, pw;
     fc_same_pad(H, &Ho, &ph);
     fc_same_pad(W, &Wo, &pw);
@@ -175,11 +176,11 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
         sh[i] = beta[c0 + i] - mu * sc[i];
     }
     const long npix = (long)B * Ho * Wo;
-    for (long pix = (long)blockIdx.x * slots + slot; pix < npix; pix += (long)gridDim.x * slots) {
-        const int wo = (int)(pix % Wo);
-        const long q = pix / Wo;
+    for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
+        const int q = pix / Wo, wo = pix - q * Wo;
+        const int b = q / Ho, ho = q - b * Ho;
         float a[FC_K];
-        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        fc_taps(in, H, W, b, ho, wo, ph, pw, a);
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -191,12 +192,12 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
             bf16x8_t o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = fc_store_cast<bf16_t>(relu6f(fmaf(acc[i], sc[i], sh[i])));
-            *(bf16x8_t*)((bf16_t*)out + pix * C + c0) = o;
+            *(bf16x8_t*)((bf16_t*)out + (long)pix * C + c0) = o;
         } else {
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = relu6f(fmaf(acc[i], sc[i], sh[i]));
-            float* op = (float*)out + pix * C + c0;
+            float* op = (float*)out + (long)pix * C + c0;
             *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
             *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
 
 static int fc_check(const char* name, int B, int H, int W, int C, int dtype) {
     ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, ATHENA_E_SHAPE, "%s: bad shape", name);
+    ATHENA_REQUIRE((long)B * H * W < (1L << 31), ATHENA_E_SHAPE, "%s: input too large", name);
     ATHENA_REQUIRE(C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, ATHENA_E_UNSUPPORTED,
                    "%s: channel count %d must be 8 * a divisor of 256", name, C);
     ATHENA_REQUIRE(dtype == ATHENA_F32 || dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "%s: dtype", name);
@@ -256,17 +258,17 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
     for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
     __syncthreads();
     const long npix = (long)B * Ho * Wo;
-    for (long pix = (long)blockIdx.x * slots + slot; pix < npix; pix += (long)gridDim.x * slots) {
-        const int wo = (int)(pix % Wo);
-        const long q = pix / Wo;
+    for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
+        const int q = pix / Wo, wo = pix - q * Wo;
+        const int b = q / Ho, ho = q - b * Ho;
         float a[FC_K], gv[8];
-        fc_taps(in, H, W, (int)(q / Ho), (int)(q % Ho), wo, ph, pw, a);
+        fc_taps(in, H, W, b, ho, wo, ph, pw, a);
         if (sizeof(T) == 2) {
-            const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + pix * C + c0);
+            const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + (long)pix * C + c0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) gv[i] = (float)h[i];
         } else {
-            const float* gp = (const float*)g + pix * C + c0;
+            const float* gp = (const float*)g + (long)pix * C + c0;
             const float4 h0 = *(const float4*)gp, h1 = *(const float4*)(gp + 4);
             gv[0] = h0.x; gv[1] = h0.y; gv[2] = h0.z; gv[3] = h0.w;
             gv[4] = h1.x; gv[5] = h1.y; gv[6] = h1.z; gv[7] = h1.w;
@@ -288,7 +290,27 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
     for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) dst[i] = red[i];
 }
 
-__global__ void fc_bwd_final_kernel(const float* __restrict__ partial, int nblk, const double* __restrict__ mom,
+// sums the slabs: workgroup = 64 entries (t, c) x 4 waves, each wave takes a quarter of the slabs
+__global__ __launch_bounds__(256) void fc_bwd_fold_kernel(const float* __restrict__ partial, int nblk, int nent,
+                                                          double* __restrict__ tot) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    double a0 = 0.0, a1 = 0.0;
+    if (e < nent) {
+        int b = w;
+        for (; b + 4 < nblk; b += 8) {
+            a0 += (double)partial[(long)b * nent + e];
+            a1 += (double)partial[(long)(b + 4) * nent + e];
+        }
+        if (b < nblk) a0 += (double)partial[(long)b * nent + e];
+    }
+    red[w][lane] = a0 + a1;
+    __syncthreads();
+    if (w == 0 && e < nent) tot[e] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ void fc_bwd_final_kernel(const double* __restrict__ tot, const double* __restrict__ mom,
                                     const float* __restrict__ w, const float* __restrict__ mean_rstd,
                                     const float* __restrict__ gamma, long npix, int C, float* __restrict__ dw,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -296,12 +318,7 @@ __global__ void fc_bwd_final_kernel(const float* __restrict__ partial, int nblk,
     if (c >= C) return;
     double T[FC_K + 1];
 #pragma unroll
-    for (int t = 0; t <= FC_K; ++t) T[t] = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* src = partial + (long)b * (FC_K + 1) * C + c;
-#pragma unroll
-        for (int t = 0; t <= FC_K; ++t) T[t] += (double)src[t * C];
-    }
+    for (int t = 0; t <= FC_K; ++t) T[t] = tot[t * C + c];
     const double sb = T[FC_K];
     const double mu = (double)mean_rstd[c], rs = (double)mean_rstd[C + c], ga = (double)gamma[c];
     const double n = (double)npix;
@@ -325,7 +342,8 @@ __global__ void fc_bwd_final_kernel(const float* __restrict__ partial, int nblk,
 }
 
 extern "C" int64_t athena_conv1_bn_bwd_workspace_bytes(int Cout) {
-    return (int64_t)sizeof(float) * FC_BWD_BLOCKS * (FC_K + 1) * (Cout > 0 ? Cout : 0);
+    const int64_t nent = (int64_t)(FC_K + 1) * (Cout > 0 ? Cout : 0);
+    return (int64_t)sizeof(float) * FC_BWD_BLOCKS * nent + (int64_t)sizeof(double) * nent;   // slabs + totals
 }
 
 extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const float* w_hwio, const double* moments,
@@ -355,8 +373,12 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const float* 
     else
         hipLaunchKernelGGL(fc_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const float*)g, B, H,
                            W, Cout, Ho, Wo, ph, pw, (float*)workspace);
-    hipLaunchKernelGGL(fc_bwd_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, (const float*)workspace, (int)blocks,
-                       moments, w_hwio, mean_rstd, gamma, npix, Cout, dw_hwio, dgamma, dbeta);
+    const int nent = (FC_K + 1) * Cout;
+    double* tot = (double*)((char*)workspace + sizeof(float) * (size_t)FC_BWD_BLOCKS * nent);   // 8-byte aligned
+    hipLaunchKernelGGL(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,
+                       nent, tot);
+    hipLaunchKernelGGL(fc_bwd_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, (const double*)tot, moments, w_hwio,
+                       mean_rstd, gamma, npix, Cout, dw_hwio, dgamma, dbeta);
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_bwd");
     return ATHENA_OK;
 }

@@ -117,7 +117,7 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     if (rc) return rc;
     if (reduce) {
         const long work = (long)(d->M + 1) * (p.epi.ldp / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, d->M, d->N, p.epi.ldp, (float*)d->C, d->ldc, 0L, d->alpha,
                            p.epi.bsum);
         ATHENA_CHECK_LAUNCH("athena_gemm(split-k reduce)");
@@ -310,7 +310,7 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     if (rc) return rc;
     if (partial) {
         const long work = (long)(Cin + 1) * (p.epi.ldp / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), 9), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 9), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, Cin, Cout, p.epi.ldp, dw_hwio, Cout, (long)Cin * Cout, 1.f,
                            (float*)nullptr);
         ATHENA_CHECK_LAUNCH("athena_conv3x3s2_wgrad(split-k reduce)");

@@ -810,18 +810,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int ldp, float* __restrict__ C, int ldc,
                                                             long c_batch_stride, float alpha,
                                                             float* __restrict__ bsum) {
+    // workgroup = 64 column quads x 4 waves; wave w adds slabs w, w + 4, ... and the four partial
+    // sums meet in LDS (fixed order: the result does not depend on scheduling)
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = ldp >> 2;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)blockIdx.x * 64 + lane;
     const int row = (int)(idx / q), n = (int)(idx % q) * 4;
-    if (row > M || n >= N || (row == M && !bsum)) return;
+    const bool live = row <= M && n < N && (row < M || bsum);
     const long slab = (long)(M + 1) * ldp;
-    const float* src = partial + (long)blockIdx.y * split * slab + (long)row * ldp + n;
-    float4 s = *(const float4*)src;
-    for (int i = 1; i < split; ++i) {
-        const float4 t = *(const float4*)(src + i * slab);
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (live) {
+        const float* src = partial + (long)blockIdx.y * split * slab + (long)row * ldp + n;
+        int i = w;
+        for (; i + 4 < split; i += 8) {
+            const float4 a = *(const float4*)(src + (long)i * slab);
+            const float4 b = *(const float4*)(src + (long)(i + 4) * slab);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (i < split) {
+            const float4 a = *(const float4*)(src + (long)i * slab);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
     }
-    const float v[4] = {s.x, s.y, s.z, s.w};
+    red[w][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (w != 0 || !live) return;
+    const float4 r0 = red[0][lane], r1 = red[1][lane], r2 = red[2][lane], r3 = red[3][lane];
+    const float v[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                        (r0.w + r1.w) + (r2.w + r3.w)};
     if (row == M) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)

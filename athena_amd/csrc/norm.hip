@@ -246,47 +246,62 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
     __syncthreads();
     const int r0 = blockIdx.x * LNV_ROWS_PER_BLOCK;
     const int r1 = min(rows, r0 + LNV_ROWS_PER_BLOCK);
-    for (int rb = r0; rb < r1; rb += rpp) {
-        const int row = rb + gi;
-        const bool live = row < r1 && col_ok;
-        const int rc = row < r1 ? row : r1 - 1;
-        const long base = (long)rc * d + c0;
-        const float mu = mean[rc], rs = rstd[rc];
-        float dyv[8], x[8], gy[8];
-        Vec8<T>::load(dy + base, dyv);
-        Vec8<T>::load(z + base, x);
-        float c1 = 0.f, c2 = 0.f;
+    // two row passes per trip, all four loads issued before any arithmetic
+    for (int rb = r0; rb < r1; rb += 2 * rpp) {
+        int rowv[2];
+        bool livev[2];
+        long basev[2];
+        float dyv[2][8], x[2][8], muv[2], rsv[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            dyv[i] = live ? dyv[i] : 0.f;
-            x[i] = live ? (x[i] - mu) * rs : 0.f;
-            gy[i] = dyv[i] * g[i];
-            pg[i] += dyv[i] * x[i];
-            pb[i] += dyv[i];
-            c1 += gy[i];
-            c2 += gy[i] * x[i];
+        for (int u = 0; u < 2; ++u) {
+            rowv[u] = rb + u * rpp + gi;
+            livev[u] = rowv[u] < r1 && col_ok;
+            const int rc = rowv[u] < r1 ? rowv[u] : r1 - 1;
+            basev[u] = (long)rc * d + c0;
+            Vec8<T>::load(dy + basev[u], dyv[u]);
+            Vec8<T>::load(z + basev[u], x[u]);
+            muv[u] = mean[rc];
+            rsv[u] = rstd[rc];
         }
-        c1 = group_sum(c1, G) / d;
-        c2 = group_sum(c2, G) / d;
-        if (live) {
-            float dz[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) dz[i] = rs * (gy[i] - c1 - x[i] * c2);
-            if (accumulate_da) {
-                float old[8];
-                Vec8<T>::load(da + base, old);
+        for (int u = 0; u < 2; ++u) {
+            const bool live = livev[u];
+            const long base = basev[u];
+            const float mu = muv[u], rs = rsv[u];
+            float gy[8];
+            float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) old[i] += dz[i];
-                Vec8<T>::store(da + base, old);
-            } else {
-                Vec8<T>::store(da + base, dz);
+            for (int i = 0; i < 8; ++i) {
+                dyv[u][i] = live ? dyv[u][i] : 0.f;
+                x[u][i] = live ? (x[u][i] - mu) * rs : 0.f;
+                gy[i] = dyv[u][i] * g[i];
+                pg[i] += dyv[u][i] * x[u][i];
+                pb[i] += dyv[u][i];
+                c1 += gy[i];
+                c2 += gy[i] * x[u][i];
             }
-            if (db) {
-                if (thresh) {
+            c1 = group_sum(c1, G) / d;
+            c2 = group_sum(c2, G) / d;
+            if (live) {
+                float dz[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dz[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+                for (int i = 0; i < 8; ++i) dz[i] = rs * (gy[i] - c1 - x[u][i] * c2);
+                if (accumulate_da) {
+                    float old[8];
+                    Vec8<T>::load(da + base, old);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) old[i] += dz[i];
+                    Vec8<T>::store(da + base, old);
+                } else {
+                    Vec8<T>::store(da + base, dz);
                 }
-                Vec8<T>::store(db + base, dz);
+                if (db) {
+                    if (thresh) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) dz[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+                    }
+                    Vec8<T>::store(db + base, dz);
+                }
             }
         }
     }
