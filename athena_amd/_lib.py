@@ -45,6 +45,7 @@ _SIGNATURES = {
     "athena_last_error": (c_char_p, []),
     "athena_abi_version": (c_int, []),
     "athena_gemm": (c_int, [POINTER(GemmDesc), _S]),
+    "athena_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _S]),
     "athena_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "athena_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,

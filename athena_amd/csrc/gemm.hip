@@ -36,7 +36,7 @@ static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     e.rng_site = d->rng_site;
 }
 
-extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
+static int gemm_validate(const athena_gemm_desc* d) {
     ATHENA_REQUIRE(d && d->A && d->B && d->C, ATHENA_E_SHAPE, "athena_gemm: null operand");
     ATHENA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, ATHENA_E_SHAPE, "athena_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
     ATHENA_REQUIRE(d->split_k >= 0 && d->split_k <= 1024, ATHENA_E_SHAPE, "athena_gemm: bad split_k %d", d->split_k);
@@ -46,8 +46,6 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     const int b_cols = d->trans_b ? d->K : d->N;
     ATHENA_REQUIRE(d->lda >= a_cols && d->ldb >= b_cols && d->ldc >= d->N, ATHENA_E_SHAPE,
                    "athena_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", d->lda, d->ldb, d->ldc);
-    const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->in_dtype, 1, d->split_k == 0);
-    const int split = d->split_k == 0 ? plan.split : d->split_k;
     if (d->split_k != 1)
         ATHENA_REQUIRE(d->out_dtype == ATHENA_F32 && d->act == ATHENA_ACT_NONE && !d->bias && !d->C_pre &&
                            d->drop_p == 0.f && !d->accumulate,
@@ -65,7 +63,15 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
         ATHENA_REQUIRE(d->trans_b || d->ldb >= (d->N + 7) / 8 * 8, ATHENA_E_ALIGN, "athena_gemm: !trans_b needs ldb >= roundup8(N) (N=%d ldb=%d)", d->N, d->ldb);
         ATHENA_REQUIRE(athena_aligned16(d->A) && athena_aligned16(d->B), ATHENA_E_ALIGN, "athena_gemm: operands must be 16-byte aligned");
     }
-    GemmProblem<PlainRows> p;
+    if (d->b_colsum) {
+        ATHENA_REQUIRE(d->trans_a && !d->trans_b, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum needs trans_a && !trans_b");
+        ATHENA_REQUIRE(d->split_k <= 1, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum with an explicit split_k > 1 is not supported");
+    }
+    return ATHENA_OK;
+}
+
+// problem description for ``split`` K splits; partial != null: raw partial sums go there
+static void gemm_fill(const athena_gemm_desc* d, int split, float* partial, GemmProblem<PlainRows>& p) {
     memset(&p, 0, sizeof(p));
     p.A = d->A;
     p.B = d->B;
@@ -75,52 +81,169 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     p.nseg = 1;
     p.kseg = d->K;
     p.ldb = d->ldb;
-    p.seg_base = 0;
     p.split_k = split;
     fill_epilogue(p.epi, d);
-    const bool bf = d->in_dtype == ATHENA_BF16;
-    if (d->b_colsum) {
-        ATHENA_REQUIRE(d->trans_a && !d->trans_b, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum needs trans_a && !trans_b");
-        if (!bf) {
-            // fp32 operands: the column sums come from the stand-alone reduction
-            p.epi.bsum = nullptr;
-            int rc = athena_colsum(d->B, d->in_dtype, d->K, d->N, d->ldb, d->b_colsum, stream);
-            if (rc) return rc;
-        }
+    if (d->in_dtype != ATHENA_BF16) p.epi.bsum = nullptr;     // fp32 operands: stand-alone column sums
+    p.epi.atomic = split > 1 ? 1 : 0;
+    if (split > 1 && partial) {
+        p.epi.atomic = 2;
+        p.epi.partial = partial;
+        p.epi.ldp = (d->N + 7) / 8 * 8;
     }
-    p.epi.atomic = split > 1;
-    bool reduce = false;
-    if (d->split_k == 0 && split > 1) {
-        if (d->workspace && (size_t)d->workspace_bytes >= splitk_workspace_bytes(d->M, d->N, split, 1) &&
-            athena_aligned16(d->workspace)) {
-            // partial sums go to the workspace; a second kernel adds them up in a fixed order
-            p.epi.atomic = 2;
-            p.epi.partial = (float*)d->workspace;
-            p.epi.ldp = (d->N + 7) / 8 * 8;
-            reduce = true;
-        } else {
-            // no workspace: fp32 atomics onto a zero-filled output
-            hipError_t e = (d->ldc == d->N)
-                               ? hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, (hipStream_t)stream)
-                               : hipMemset2DAsync(d->C, sizeof(float) * (size_t)d->ldc, 0, sizeof(float) * (size_t)d->N, d->M, (hipStream_t)stream);
-            ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
-            if (p.epi.bsum) {
-                e = hipMemsetAsync(p.epi.bsum, 0, sizeof(float) * (size_t)d->N, (hipStream_t)stream);
-                ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
-            }
-        }
-    } else if (split > 1 && p.epi.bsum) {
-        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_gemm: b_colsum with an explicit split_k > 1 is not supported");
+}
+
+static int gemm_zero_fill_for_atomics(const athena_gemm_desc* d, float* bsum, hipStream_t stream) {
+    hipError_t e = (d->ldc == d->N)
+                       ? hipMemsetAsync(d->C, 0, sizeof(float) * (size_t)d->M * d->N, stream)
+                       : hipMemset2DAsync(d->C, sizeof(float) * (size_t)d->ldc, 0, sizeof(float) * (size_t)d->N, d->M, stream);
+    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
+    if (bsum) {
+        e = hipMemsetAsync(bsum, 0, sizeof(float) * (size_t)d->N, stream);
+        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_gemm: memset failed");
     }
-    p.crow_mode = 0;
-    int rc = launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, plan.bt, (hipStream_t)stream);
+    return ATHENA_OK;
+}
+
+extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
+    int rc = gemm_validate(d);
     if (rc) return rc;
-    if (reduce) {
+    const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->in_dtype, 1, d->split_k == 0);
+    const int split = d->split_k == 0 ? plan.split : d->split_k;
+    if (d->b_colsum && d->in_dtype != ATHENA_BF16) {
+        rc = athena_colsum(d->B, d->in_dtype, d->K, d->N, d->ldb, d->b_colsum, stream);
+        if (rc) return rc;
+    }
+    const bool use_ws = d->split_k == 0 && split > 1 && d->workspace && athena_aligned16(d->workspace) &&
+                        (size_t)d->workspace_bytes >= splitk_workspace_bytes(d->M, d->N, split, 1);
+    GemmProblem<PlainRows> p;
+    gemm_fill(d, split, use_ws ? (float*)d->workspace : nullptr, p);
+    if (d->split_k == 0 && split > 1 && !use_ws) {
+        // no workspace: fp32 atomics onto a zero-filled output
+        rc = gemm_zero_fill_for_atomics(d, p.epi.bsum, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    rc = launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, plan.bt, (hipStream_t)stream);
+    if (rc) return rc;
+    if (use_ws) {
+        // the partial sums are added up by a second kernel in a fixed order
         const long work = (long)(d->M + 1) * (p.epi.ldp / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, d->M, d->N, p.epi.ldp, (float*)d->C, d->ldc, 0L, d->alpha,
                            p.epi.bsum);
         ATHENA_CHECK_LAUNCH("athena_gemm(split-k reduce)");
+    }
+    return ATHENA_OK;
+}
+
+template <int WT>
+static void launch_grouped(const GemmGroup& g, bool ta, bool tb, int blocks, hipStream_t stream) {
+    const dim3 grid((unsigned)blocks);
+    if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, true, WT>), grid, dim3(256), 0, stream, g);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, false, WT>), grid, dim3(256), 0, stream, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<true, false, WT>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_mfma_grouped_kernel<true, true, WT>), grid, dim3(256), 0, stream, g);
+}
+
+extern "C" int athena_gemm_grouped(const athena_gemm_desc* descs, int count, athena_stream_t stream) {
+    ATHENA_REQUIRE(descs && count > 0, ATHENA_E_SHAPE, "athena_gemm_grouped: empty group");
+    bool uniform = true, all_auto = true, any_auto = false;
+    for (int i = 0; i < count; ++i) {
+        int rc = gemm_validate(&descs[i]);
+        if (rc) return rc;
+        uniform = uniform && descs[i].trans_a == descs[0].trans_a && descs[i].trans_b == descs[0].trans_b &&
+                  descs[i].in_dtype == descs[0].in_dtype;
+        all_auto = all_auto && descs[i].split_k == 0;
+        any_auto = any_auto || descs[i].split_k == 0;
+        ATHENA_REQUIRE(descs[i].split_k <= 1, ATHENA_E_UNSUPPORTED, "athena_gemm_grouped: split_k must be 0 or 1");
+    }
+    // one launch needs bf16 operands, one operand layout and either all or no automatic splits
+    if (count == 1 || !uniform || descs[0].in_dtype != ATHENA_BF16 || (any_auto && !all_auto)) {
+        for (int i = 0; i < count; ++i) {
+            int rc = athena_gemm(&descs[i], stream);
+            if (rc) return rc;
+        }
+        return ATHENA_OK;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int g0 = 0; g0 < count; g0 += GEMM_GROUP_MAX) {
+        const athena_gemm_desc* d = descs + g0;
+        const int n = count - g0 < GEMM_GROUP_MAX ? count - g0 : GEMM_GROUP_MAX;
+        // tile edge for the whole group, then one split factor per problem
+        long t128 = 0, t64 = 0, min_k8 = 1L << 40;
+        bool big = true;
+        for (int i = 0; i < n; ++i) {
+            t128 += gemm_tiles(d[i].M, d[i].N, 128);
+            t64 += gemm_tiles(d[i].M, d[i].N, 64);
+            big = big && d[i].M > 64 && d[i].N > 64;
+            const long k8 = ((d[i].K + GM_BK - 1) / GM_BK) / 8;
+            min_k8 = k8 < min_k8 ? k8 : min_k8;
+        }
+        if (min_k8 < 1) min_k8 = 1;
+        const bool bt128 = big && (t128 >= 192 || (all_auto && t128 * min_k8 >= 256));
+        const int bt = bt128 ? 128 : 64;
+        const long base = bt128 ? t128 : t64;
+        long want = all_auto ? (640 + base - 1) / base : 1;
+        GemmGroup grp;
+        ReduceGroup red;
+        memset(&grp, 0, sizeof(grp));
+        memset(&red, 0, sizeof(red));
+        size_t ws_need = 0;
+        int splits[GEMM_GROUP_MAX];
+        for (int i = 0; i < n; ++i) {
+            const long ktiles = (d[i].K + GM_BK - 1) / GM_BK;
+            long si = want, cap = ktiles / (bt128 ? 8 : 4);
+            if (si > cap) si = cap;
+            if (si < 1) si = 1;
+            splits[i] = (int)si;
+            if (si > 1) ws_need += splitk_workspace_bytes(d[i].M, d[i].N, (int)si, 1);
+        }
+        char* ws = (char*)d[0].workspace;
+        if (ws_need > 0 && !(ws && athena_aligned16(ws) && (size_t)d[0].workspace_bytes >= ws_need)) {
+            // no room for the partial sums: run the problems one by one
+            for (int i = 0; i < n; ++i) {
+                int rc = athena_gemm(&d[i], stream);
+                if (rc) return rc;
+            }
+            continue;
+        }
+        int blocks = 0, rblocks = 0;
+        grp.count = n;
+        for (int i = 0; i < n; ++i) {
+            float* partial = nullptr;
+            if (splits[i] > 1) {
+                partial = (float*)ws;
+                ws += splitk_workspace_bytes(d[i].M, d[i].N, splits[i], 1);
+            }
+            gemm_fill(&d[i], splits[i], partial, grp.p[i]);
+            grp.first[i] = blocks;
+            grp.tiles_m[i] = (d[i].M + bt - 1) / bt;
+            grp.tiles_n[i] = (d[i].N + bt - 1) / bt;
+            blocks += grp.tiles_m[i] * grp.tiles_n[i] * splits[i];
+            if (splits[i] > 1) {
+                const int j = red.count++;
+                red.first[j] = rblocks;
+                red.partial[j] = partial;
+                red.C[j] = (float*)d[i].C;
+                red.bsum[j] = grp.p[i].epi.bsum;
+                red.split[j] = splits[i];
+                red.M[j] = d[i].M;
+                red.N[j] = d[i].N;
+                red.ldp[j] = grp.p[i].epi.ldp;
+                red.ldc[j] = d[i].ldc;
+                red.alpha[j] = d[i].alpha;
+                const long work = (long)(d[i].M + 1) * (grp.p[i].epi.ldp / 4);
+                rblocks += (int)((work + 63) / 64);
+            }
+        }
+        grp.first[n] = blocks;
+        red.first[red.count] = rblocks;
+        if (bt128) launch_grouped<4>(grp, d[0].trans_a != 0, d[0].trans_b != 0, blocks, s);
+        else launch_grouped<2>(grp, d[0].trans_a != 0, d[0].trans_b != 0, blocks, s);
+        ATHENA_CHECK_LAUNCH("athena_gemm_grouped");
+        if (red.count > 0) {
+            hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, red);
+            ATHENA_CHECK_LAUNCH("athena_gemm_grouped(split-k reduce)");
+        }
     }
     return ATHENA_OK;
 }

@@ -272,12 +272,14 @@ __device__ __forceinline__ bf16x8_t lds_frag_tr(const bf16_t* img, int col0, int
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// One workgroup's share of a problem: output tile (bx, by), K split / batch index bz.  ``p`` lives in
+// the kernel arguments and is never written (a modified by-value struct would be spilled to
+// scratch memory).
 template <class AMap, bool TA, bool TB, int WT>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) {
-    // independent problems stacked in grid.z (the kernel argument itself is never written:
-    // a modified by-value struct would be spilled to scratch memory)
-    const int zb = p.zbatch > 1 ? (int)(blockIdx.z / p.split_k) : 0;
-    const int zsplit = p.zbatch > 1 ? (int)(blockIdx.z % p.split_k) : (int)blockIdx.z;
+__device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const int bx, const int by, const int bz) {
+    // independent problems stacked in grid.z
+    const int zb = p.zbatch > 1 ? (int)(bz / p.split_k) : 0;
+    const int zsplit = p.zbatch > 1 ? (int)(bz % p.split_k) : (int)bz;
     const int seg_base = p.seg_base + zb;
     const long coff = (long)zb * p.c_batch_stride;
     constexpr int BT = 32 * WT;                       // tile edge
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int bm = blockIdx.x * BT;
-    const int bn = blockIdx.y * BT;
+    const int bm = bx * BT;
+    const int bn = by * BT;
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
     const bf16_t* __restrict__ B = (const bf16_t*)p.B;
 
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
     // column sums of B (bias gradient of a weight-gradient GEMM): in the first row of workgroups
     // the waves with wm == 0 multiply their B fragments with an all-ones A fragment as well, which
     // leaves sum_k B(k, n) in every column of one extra accumulator per 16 columns
-    const bool want_bsum = !TB && p.epi.bsum != nullptr && blockIdx.x == 0 && wm == 0;
+    const bool want_bsum = !TB && p.epi.bsum != nullptr && bx == 0 && wm == 0;
     f32x4_t bs[WT];
 #pragma unroll
     for (int j = 0; j < WT; ++j) bs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
                 const int n = bn + wn * 16 * WT + j * 16 + 4 * (lane >> 4) + r;
                 if (n < p.N) {
                     const float t = bs[j][r];
-                    if (p.epi.atomic == 2) p.epi.partial[((long)blockIdx.z * (p.M + 1) + p.M) * p.epi.ldp + n] = t;
+                    if (p.epi.atomic == 2) p.epi.partial[((long)bz * (p.M + 1) + p.M) * p.epi.ldp + n] = t;
                     else if (p.epi.atomic == 1) atomicAdd(p.epi.bsum + n, t);
                     else p.epi.bsum[n] = t;
                 }
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
             for (int row = row0; row < BT && bm + row < p.M; row += RSTEP) {
                 float v[8];
                 read_piece(row, v);
-                float* c = e.partial + ((long)blockIdx.z * (p.M + 1) + out_row(p, bm + row)) * e.ldp + n;
+                float* c = e.partial + ((long)bz * (p.M + 1) + out_row(p, bm + row)) * e.ldp + n;
                 *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
@@ -694,6 +696,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) 
             if (bn + col < p.N) atomicAdd(e.colsum + which * p.N + bn + col, (double)t);
         }
     }
+}
+
+template <class AMap, bool TA, bool TB, int WT>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) {
+    gemm_mfma_body<AMap, TA, TB, WT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent problems (same operand layouts) in one launch: the workgroups of all
+// problems are numbered consecutively along grid.x; first[i] is the first workgroup of problem i.
+#define GEMM_GROUP_MAX 12
+struct GemmGroup {
+    int count;
+    int first[GEMM_GROUP_MAX + 1];
+    int tiles_m[GEMM_GROUP_MAX], tiles_n[GEMM_GROUP_MAX];
+    GemmProblem<PlainRows> p[GEMM_GROUP_MAX];
+};
+
+template <bool TA, bool TB, int WT>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_grouped_kernel(GemmGroup g) {
+    int pi = 0;
+    while (pi + 1 < g.count && (int)blockIdx.x >= g.first[pi + 1]) ++pi;
+    const int local = blockIdx.x - g.first[pi];
+    const int tm = g.tiles_m[pi], tn = g.tiles_n[pi];
+    const int bx = local % tm, r = local / tm;
+    gemm_mfma_body<PlainRows, TA, TB, WT>(g.p[pi], bx, r % tn, r / tn);
 }
 
 // ------------------------------------------------------------------ VALU core (fp32)
@@ -859,6 +886,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static inline size_t splitk_workspace_bytes(int M, int N, int split, int zbatch) {
     const size_t ldp = (size_t)(N + 7) / 8 * 8;
     return sizeof(float) * (size_t)(zbatch > 1 ? zbatch : 1) * split * (size_t)(M + 1) * ldp;
+}
+
+struct ReduceGroup {
+    int count;
+    int first[GEMM_GROUP_MAX + 1];
+    const float* partial[GEMM_GROUP_MAX];
+    float* C[GEMM_GROUP_MAX];
+    float* bsum[GEMM_GROUP_MAX];
+    int split[GEMM_GROUP_MAX], M[GEMM_GROUP_MAX], N[GEMM_GROUP_MAX], ldp[GEMM_GROUP_MAX], ldc[GEMM_GROUP_MAX];
+    float alpha[GEMM_GROUP_MAX];
+};
+
+// splitk_reduce_kernel for the problems of a grouped launch
+__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(ReduceGroup g) {
+    __shared__ float4 red[4][64];
+    int pi = 0;
+    while (pi + 1 < g.count && (int)blockIdx.x >= g.first[pi + 1]) ++pi;
+    const float* __restrict__ partial = g.partial[pi];
+    const int split = g.split[pi], M = g.M[pi], N = g.N[pi], ldp = g.ldp[pi], ldc = g.ldc[pi];
+    float* __restrict__ C = g.C[pi];
+    float* __restrict__ bsum = g.bsum[pi];
+    const float alpha = g.alpha[pi];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = ldp >> 2;
+    const long idx = (long)(blockIdx.x - g.first[pi]) * 64 + lane;
+    const int row = (int)(idx / q), n = (int)(idx % q) * 4;
+    const bool live = row <= M && n < N && (row < M || bsum);
+    const long slab = (long)(M + 1) * ldp;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (live) {
+        const float* src = partial + (long)row * ldp + n;
+        int i = w;
+        for (; i + 4 < split; i += 8) {
+            const float4 a = *(const float4*)(src + (long)i * slab);
+            const float4 b = *(const float4*)(src + (long)(i + 4) * slab);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (i < split) {
+            const float4 a = *(const float4*)(src + (long)i * slab);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[w][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (w != 0 || !live) return;
+    const float4 r0 = red[0][lane], r1 = red[1][lane], r2 = red[2][lane], r3 = red[3][lane];
+    const float v[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                        (r0.w + r1.w) + (r2.w + r3.w)};
+    if (row == M) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) bsum[n + r] = v[r];
+        return;
+    }
+    float* c = C + (long)row * ldc + n;
+    if (n + 3 < N && (ldc & 3) == 0 && ((((uintptr_t)C) & 15) == 0)) {
+        *(float4*)c = make_float4(v[0] * alpha, v[1] * alpha, v[2] * alpha, v[3] * alpha);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) c[r] = v[r] * alpha;
+    }
 }
 
 // number of workgroups a launch would use with tile edge ``bt``

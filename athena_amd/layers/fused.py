@@ -40,6 +40,23 @@ def lin_fwd(x, M, dense, act=ACT_NONE, want_pre=False, drop_p=0.0, rng=None, sit
     return out, pre
 
 
+def lin_fwd_group(items):
+    """y_i = x_i @ kernel_i + bias_i for several Dense layers at once (one grouped launch)."""
+    outs, problems = [], []
+    for x, M, dense in items:
+        K, N = dense.in_features, dense.out_features
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        outs.append(out)
+        if x.dtype == torch.bfloat16:
+            problems.append((x, dense.shadow_t, out, M, N, K, dict(trans_b=True, lda=K, ldb=dense.shadow_t.shape[1],
+                                                                   ldc=N, bias=dense.bias)))
+        else:
+            problems.append((x, dense.kernel, out, M, N, K, dict(trans_b=False, lda=K, ldb=N, ldc=N,
+                                                                 bias=dense.bias)))
+    ops.gemm_grouped(problems)
+    return outs
+
+
 def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=None, drop_p=0.0, rng=None,
               site=0):
     """dx[M,K] (+)= (dy[M,N] @ kernel^T) * act'(aux) * dropout."""
@@ -59,11 +76,36 @@ def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=
     return out
 
 
-def lin_bwd_w(x, dy, M, dense, ldx, lddy):
-    """kernel.grad = x^T @ dy ; bias.grad = column sums of dy."""
+class weight_grad_group:
+    """Collects the weight-gradient products issued inside the ``with`` block and runs them as one
+    grouped launch at its end: the weight gradients of a layer are independent of everything else
+    in its backward pass, and together they fill the chip where each alone does not."""
+    _open = None
+
+    def __enter__(self):
+        self.prev = weight_grad_group._open
+        self.problems = []
+        weight_grad_group._open = self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        weight_grad_group._open = self.prev
+        if exc_type is None:
+            ops.gemm_grouped(self.problems)
+        self.problems = None
+        return False
+
+
+def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):
+    """kernel.grad = x^T @ dy ; bias.grad = column sums of dy.  ``defer=False`` runs the product now
+    even inside a ``weight_grad_group`` -- needed when ``dy`` is about to be overwritten."""
     K, N = dense.in_features, dense.out_features
-    ops.gemm(x, dy, dense.kernel.grad, K, N, M, trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0,
-             b_colsum=dense.bias.grad)
+    kw = dict(trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0, b_colsum=dense.bias.grad)
+    grp = weight_grad_group._open
+    if grp is not None and defer:
+        grp.problems.append((x, dy, dense.kernel.grad, K, N, M, kw))   # keeps x and dy alive until the launch
+    else:
+        ops.gemm(x, dy, dense.kernel.grad, K, N, M, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -72,9 +114,7 @@ def lin_bwd_w(x, dy, M, dense, ldx, lddy):
 def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal):
     d, h = attn.d_model, attn.num_heads
     dk = d // h
-    q, _ = lin_fwd(q_in, B * Tq, attn.wq)
-    k, _ = lin_fwd(kv_in, B * Tk, attn.wk)
-    v, _ = lin_fwd(kv_in, B * Tk, attn.wv)
+    q, k, v = lin_fwd_group([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk), (kv_in, B * Tk, attn.wv)])
     ctx = torch.empty((B * Tq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, h, Tq), dtype=torch.float32, device=q.device)
     ops.mha_fwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, d, lse)
@@ -88,7 +128,9 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
     dk = d // h
     q, k, v, ctx, lse = saved
     Mq, Mk = B * Tq, B * Tk
-    lin_bwd_w(ctx, dout, Mq, attn.dense, d, d)
+    # without dropout the caller's dout IS the buffer the input gradients are accumulated into
+    safe = dout.data_ptr() not in (dq_in.data_ptr(), dkv_in.data_ptr())
+    lin_bwd_w(ctx, dout, Mq, attn.dense, d, d, defer=safe)
     dctx = lin_bwd_x(dout, Mq, attn.dense, d)
     dq = torch.empty_like(q)
     dk_ = torch.empty_like(k)
@@ -116,7 +158,7 @@ def ffn_bwd(df, x, M, layer, saved, p, rng, dx):
     """Parameter grads of the two Dense layers; dx += d(ffn)/dx."""
     h_pre, h = saved
     d, dff = layer.ffn0.in_features, layer.ffn0.out_features
-    lin_bwd_w(h, df, M, layer.ffn1, dff, d)
+    lin_bwd_w(h, df, M, layer.ffn1, dff, d, defer=df.data_ptr() != dx.data_ptr())
     dh = lin_bwd_x(df, M, layer.ffn1, d, act=ACT_MUL_DGELU, aux=h_pre, drop_p=p, rng=rng, site=layer.site_ffn_h)
     lin_bwd_w(x, dh, M, layer.ffn0, d, dff)
     lin_bwd_x(dh, M, layer.ffn0, dff, out=dx, accumulate=True)
@@ -158,12 +200,13 @@ class EncoderLayerFn(torch.autograd.Function):
         x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2 = ctx.saved
         ctx.saved = None
         dy = dy.contiguous().view(M, d)
-        d_y1, df = ops.add_layernorm_bwd(dy, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
-                                         layer.norm2.gamma.grad, layer.norm2.beta.grad)
-        ffn_bwd(df, y1, M, layer, s_ffn, p, rng, d_y1)
-        dx, da = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
-                                       layer.norm1.gamma.grad, layer.norm1.beta.grad)
-        mha_block_bwd(da, x2, x2, layer.self_attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
+        with weight_grad_group():
+            d_y1, df = ops.add_layernorm_bwd(dy, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
+                                             layer.norm2.gamma.grad, layer.norm2.beta.grad)
+            ffn_bwd(df, y1, M, layer, s_ffn, p, rng, d_y1)
+            dx, da = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
+                                           layer.norm1.gamma.grad, layer.norm1.beta.grad)
+            mha_block_bwd(da, x2, x2, layer.self_attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
         return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
@@ -202,16 +245,17 @@ class DecoderLayerFn(torch.autograd.Function):
         t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3 = ctx.saved
         ctx.saved = None
         dy = dy.contiguous().view(M, d)
-        d_y2, df = ops.add_layernorm_bwd(dy, z3, mean3, rstd3, layer.norm3.gamma, p, rng, layer.site_res3,
-                                         layer.norm3.gamma.grad, layer.norm3.beta.grad)
-        ffn_bwd(df, y2, M, layer, s_ffn, p, rng, d_y2)
-        d_y1, da2 = ops.add_layernorm_bwd(d_y2, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
-                                          layer.norm2.gamma.grad, layer.norm2.beta.grad)
-        dmem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
-        mha_block_bwd(da2, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, False)
-        dtgt, da1 = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
-                                          layer.norm1.gamma.grad, layer.norm1.beta.grad)
-        mha_block_bwd(da1, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True)
+        with weight_grad_group():
+            d_y2, df = ops.add_layernorm_bwd(dy, z3, mean3, rstd3, layer.norm3.gamma, p, rng, layer.site_res3,
+                                             layer.norm3.gamma.grad, layer.norm3.beta.grad)
+            ffn_bwd(df, y2, M, layer, s_ffn, p, rng, d_y2)
+            d_y1, da2 = ops.add_layernorm_bwd(d_y2, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
+                                              layer.norm2.gamma.grad, layer.norm2.beta.grad)
+            dmem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
+            mha_block_bwd(da2, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, False)
+            dtgt, da1 = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
+                                              layer.norm1.gamma.grad, layer.norm1.beta.grad)
+            mha_block_bwd(da1, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True)
         return (dtgt.view(B, L, d), dmem.view(B, T, d), None, None, None, None) + \
             (None,) * (len(ctx.needs_input_grad) - 6)
 

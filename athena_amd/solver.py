@@ -75,14 +75,49 @@ class BaseSolver:
             if m is not None and hasattr(m, "flush"):
                 m.flush()
 
-    def train_step(self, samples):
-        """train the model 1 step (solver.py:89-99)."""
-        loss, metrics = self._forward_backward(samples)
-        scale = self._reduce_gradients()
+    def _metric_objects(self):
+        out = []
+        for m in (getattr(self.model, "metric", None), getattr(getattr(self.model, "model", None), "metric", None)):
+            if m is not None and hasattr(m, "_pending") and m not in out:
+                out.append(m)
+        return out
+
+    def _update(self, scale):
         self.optimizer.apply_gradients(clip_norm=self.hparams.clip_norm, grad_scale=scale)
         ops.advance_rng(self.model.store.rng_state)
+
+    def _eager_step(self, samples):
+        loss, metrics = self._forward_backward(samples)
+        scale = self._reduce_gradients()
+        self._update(scale)
         self._flush_metrics()
         return loss, metrics
+
+    def train_step(self, samples):
+        """train the model 1 step (solver.py:89-99).
+
+        ``enable_tf_function`` (the reference compiles the step with tf.function, solver.py:91-93)
+        selects HIP-graph replay here: the first step on a new batch shape runs eagerly, the second
+        one records forward + backward + update into a HIP graph, and every later step copies the
+        batch into the recorded input buffers and replays the graph.  The returned loss tensors are
+        the graph's output buffers: read them before the next step."""
+        if not self._graphable(samples):
+            return self._eager_step(samples)
+        key = _shape_key(samples)
+        state = self._graphs.get(key)
+        if state is None:                    # first sight of this shape: plain step (also the warm-up)
+            self._graphs[key] = False
+            return self._eager_step(samples)
+        if state is False:
+            state = self._graphs[key] = _GraphStep(self, samples)
+        return state.run(samples)
+
+    def _graphable(self, samples):
+        if not getattr(self.hparams, "enable_tf_function", False) or not isinstance(samples, dict):
+            return False
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        return all(isinstance(v, torch.Tensor) and v.is_cuda for v in samples.values())
 
     def train(self, dataset, total_batches=-1):
         """Update the model in 1 epoch (solver.py:101-113)."""
@@ -123,6 +158,56 @@ class BaseSolver:
             logging.info(self.metric_checker(mean_loss, metrics, evaluate_epoch=epoch))
         self.model.reset_metrics()
         return mean_loss, metrics
+
+
+def _shape_key(samples):
+    return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(samples.items()))
+
+
+class _GraphStep:
+    """One training step recorded as HIP graphs for one batch shape.
+
+    Single process: one graph holds forward, backward, clip + Adam and the dropout-counter bump.
+    Data parallel: the gradient all-reduce stays outside (between a forward/backward graph and an
+    update graph), so no collective is recorded.  Metric hand-over: the arg-max kernels recorded in
+    the graph leave their ids in fixed device buffers; after every replay these are copied to fresh
+    pinned host buffers and queued for the usual deferred host-side scoring."""
+
+    def __init__(self, solver, samples):
+        self.solver = solver
+        self.inputs = {k: v.clone() for k, v in samples.items()}
+        metrics_objs = solver._metric_objects()
+        before = [len(m._pending) for m in metrics_objs]
+        split = solver.world_size > 1
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.metrics = solver._forward_backward(self.inputs)
+            if not split:
+                solver._update(1.0)
+        self.update_graph = None
+        if split:
+            self.update_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.update_graph, pool=self.graph.pool()):
+                solver._update(1.0 / solver.world_size)
+        # the deferred scorers queued while recording become templates
+        self.templates = []
+        for m, n in zip(metrics_objs, before):
+            self.templates.append((m, m._pending[n:]))
+            del m._pending[n:]
+
+    def run(self, samples):
+        from .metrics import _Deferred
+        for k, v in self.inputs.items():
+            v.copy_(samples[k], non_blocking=True)
+        self.graph.replay()
+        if self.update_graph is not None:
+            self.solver._reduce_gradients()
+            self.update_graph.replay()
+        for m, items in self.templates:
+            for t in items:
+                m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
+        return self.loss, self.metrics
 
 
 def bucket_ranges(seg_offsets, n_total, bucket_elems):

@@ -104,6 +104,46 @@ def test_gemm_weight_gradient(ops, cd, rows, K, N, ldx, ldy):
 
 
 @pytest.mark.parametrize("cd", DTYPES)
+def test_gemm_grouped(ops, cd):
+    """Grouped launches give what the single launches give: weight gradients (split K, bias sums)
+    of different shapes, and projections with bias."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2000, 256, 256), (2000, 256, 1024), (2000, 1024, 256), (500, 256, 256), (2000, 72, 40), (330, 64, 4233)]
+    single, grouped, probs, keep = [], [], [], []
+    for rows, K, N in shapes:
+        ldy = (N + 7) // 8 * 8
+        x = to_cd(torch.randn(rows, K, generator=g, dtype=torch.float64), cd)
+        dy = to_cd(torch.randn(rows, ldy, generator=g, dtype=torch.float64), cd)
+        G1, b1 = torch.empty(K, N, device=dev()), torch.empty(N, device=dev())
+        G2 = torch.full((K, N), float("nan"), device=dev())
+        b2 = torch.full((N,), float("nan"), device=dev())
+        kw = dict(trans_a=True, trans_b=False, lda=K, ldb=ldy, ldc=N, split_k=0)
+        ops.gemm(x, dy, G1, K, N, rows, b_colsum=b1, **kw)
+        probs.append((x, dy, G2, K, N, rows, dict(b_colsum=b2, **kw)))
+        single.append((G1, b1))
+        grouped.append((G2, b2))
+    ops.gemm_grouped(probs)
+    for (G1, b1), (G2, b2) in zip(single, grouped):
+        assert_close(G2, G1.double().cpu(), 1e-6, "grouped weight gradient")
+        assert_close(b2, b1.double().cpu(), 1e-6, "grouped bias gradient")
+    # projections: same x, three weights, bias
+    M, K, N = 1000, 256, 256
+    x = to_cd(torch.randn(M, K, generator=g, dtype=torch.float64), cd)
+    probs, refs = [], []
+    for i in range(3):
+        w = to_cd(torch.randn(N, K, generator=g, dtype=torch.float64) * 0.1, cd)
+        b = torch.randn(N, generator=g).to(dev())
+        o1 = torch.empty(M, N, dtype=cd, device=dev())
+        o2 = torch.full((M, N), float("nan"), dtype=cd, device=dev())
+        ops.gemm(x, w, o1, M, N, K, trans_b=True, bias=b)
+        probs.append((x, w, o2, M, N, K, dict(trans_b=True, bias=b)))
+        refs.append((o1, o2))
+    ops.gemm_grouped(probs)
+    for o1, o2 in refs:
+        assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("cd", DTYPES)
 def test_gemm_dropout_consistency(ops, cd):
     """Same site + state gives the same mask in the forward and the backward epilogue."""
     M, N, K = 96, 64, 32

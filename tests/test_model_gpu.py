@@ -100,6 +100,44 @@ def test_fp32_training_steps_match_oracle():
     assert errs[0][0] <= 1e-4, "parameters after 4 steps: %s" % errs[:5]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replay_matches_eager_steps(precision):
+    """enable_tf_function: HIP-graph replay of the step follows the eager trajectory (same seeds,
+    dropout on, different batches of one shape), and the deferred metrics see every step."""
+    from athena_amd import BaseSolver, WarmUpAdam
+    from tests.modelutil import model_config
+    case = dict(TINY, mc=model_config(32, 16, 4, 2, 1, 64, rate=0.1, ls=0.1))
+    opt_cfg = dict(d_model=32, warmup_steps=3, k=0.05, decay_steps=100000, decay_rate=1.0)
+    runs = {}
+    for graph in (False, True):
+        model, samples, _ = build(case, precision)
+        opt = WarmUpAdam(dict(opt_cfg))
+        solver = BaseSolver(model, opt, config={"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": graph})
+        batches = []
+        for i in range(5):
+            s2 = {k: v.clone() for k, v in samples.items()}
+            s2["input"] = s2["input"] + 0.01 * i
+            batches.append(model.prepare_samples(s2))
+        losses = []
+        for b in batches:
+            loss, metrics = solver.train_step(b)
+            losses.append(float(loss))
+        acc = {k: float(v) for k, v in metrics.items()}
+        assert opt.iterations == 5
+        runs[graph] = (losses, acc, {k: v.clone() for k, v in model.store.state_dict().items()})
+        if graph:
+            assert any(v not in (None, False) for v in solver._graphs.values()), "no graph was recorded"
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert abs(a - b) <= tol * max(1.0, abs(a)), (runs[False][0], runs[True][0])
+    assert runs[False][1].keys() == runs[True][1].keys()
+    for k in runs[False][1]:
+        assert abs(runs[False][1][k] - runs[True][1][k]) < (1e-6 if precision == "fp32" else 0.05)
+    worst = max(rel_err(runs[True][2][k], runs[False][2][k].double().cpu()) for k in runs[False][2]
+                if not k.endswith(ZERO_GRAD))
+    assert worst <= (1e-4 if precision == "fp32" else 2e-2), worst
+
+
 @pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
 def test_bf16_logits_close_to_fp32_oracle(case):
     model, samples, ocfg = build(case, "bf16")
