@@ -75,8 +75,21 @@ def ctc_bytes(wl):
     return wl["B"] * T2 * V * 4 * 3 + wl["B"] * T2 * S * 4 * 2
 
 
+def attention_flops_per_step(wl):
+    """QK^T and PV of every attention block (forward x 3.5: the backward recomputes the scores)."""
+    B, d, U = wl["B"], wl["d_model"], wl["U"]
+    T2 = (((wl["T"] + 1) // 2) + 1) // 2
+    L = U + 1
+    fwd = wl["enc"] * 4 * T2 * T2 * d + wl["dec"] * (4 * L * L * d + 4 * L * T2 * d)
+    return 3.5 * B * fwd
+
+
 class KernelTimer:
-    """HIP-event timing of selected C-ABI entry points on the launch stream."""
+    """HIP-event timing of selected C-ABI entry points on the launch stream.
+
+    The entry points are wrapped at the ctypes level, so every launch of the step is seen.  The
+    timed step is started behind a spin kernel that keeps the GPU busy while the host enqueues the
+    whole step: the events then bracket back-to-back device execution, not host launch latency."""
 
     def __init__(self, names):
         from athena_amd import _lib
@@ -86,29 +99,64 @@ class KernelTimer:
         self._orig = {}
 
     def __enter__(self):
-        from athena_amd import ops
-        self.ops = ops
         for n in self.names:
-            fn = getattr(ops, n)
+            fn = getattr(self.lib, n)
             self._orig[n] = fn
 
-            def wrapped(*a, _fn=fn, _n=n, **k):
+            def wrapped(*a, _fn=fn, _n=n):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                r = _fn(*a, **k)
+                r = _fn(*a)
                 e1.record()
                 self.pairs[_n].append((e0, e1))
                 return r
-            setattr(ops, n, wrapped)
+            setattr(self.lib, n, wrapped)
         return self
 
     def __exit__(self, *exc):
         for n, fn in self._orig.items():
-            setattr(self.ops, n, fn)
+            setattr(self.lib, n, fn)
 
-    def total_ms(self, name):
+    def calibrate(self):
+        """Elapsed time of an event pair with nothing between (behind a busy stream): the floor
+        that every measured pair carries, subtracted in total_ms()."""
+        gpu_plug(5.0)
+        pairs = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
         torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.pairs[name]), len(self.pairs[name])
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        self.floor_ms = ts[len(ts) // 2]
+        return self.floor_ms
+
+    def total_ms(self, names):
+        torch.cuda.synchronize()
+        n = sum(len(self.pairs[k]) for k in names)
+        ms = sum(a.elapsed_time(b) for k in names for a, b in self.pairs[k]) - n * getattr(self, "floor_ms", 0.0)
+        return ms, n
+
+
+def gpu_plug(ms):
+    """Occupy the stream for about ``ms`` milliseconds."""
+    if not hasattr(gpu_plug, "cycles_per_ms"):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000000)
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(10000000)
+        e1.record()
+        torch.cuda.synchronize()
+        gpu_plug.cycles_per_ms = 10000000 / max(e0.elapsed_time(e1), 1e-3)
+    torch.cuda._sleep(int(ms * gpu_plug.cycles_per_ms))
+
+
+GEMM_ENTRIES = ["athena_gemm", "athena_gemm_grouped", "athena_conv3x3s2_fwd", "athena_conv3x3s2_dgrad",
+                "athena_conv3x3s2_wgrad"]
+ATTN_ENTRIES = ["athena_mha_fwd", "athena_mha_bwd"]
+CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd"]
 
 
 def cpu_baseline(wl, model, mc, seconds_budget=30.0):
@@ -188,33 +236,43 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
-    # per-kernel timing pass (eager, HIP events around the entry points), rank 0 only
-    roof = ctc_roof = None
+    # per-kernel timing pass (eager, HIP events around the C-ABI entry points), rank 0 only
+    roof = ctc_roof = attn_roof = None
     if rank == 0:
         was = solver.hparams.enable_tf_function
         solver.hparams.enable_tf_function = False
-        names = ["gemm", "conv3x3s2_fwd", "conv3x3s2_dgrad", "conv3x3s2_wgrad", "ctc_loss_fwd", "ctc_loss_bwd"]
         nrep = 3
         solver.train_step(ds)
-        with KernelTimer(names) as kt:
+        with KernelTimer(GEMM_ENTRIES + ATTN_ENTRIES + CTC_ENTRIES) as kt:
+            kt.calibrate()
             for _ in range(nrep):
+                gpu_plug(40.0)
                 solver.train_step(ds)
+                torch.cuda.synchronize()
         solver.hparams.enable_tf_function = was
-        g_ms = sum(kt.total_ms(n)[0] for n in names[:4])
-        g_calls = sum(kt.total_ms(n)[1] for n in names[:4])
+        g_ms, g_calls = kt.total_ms(GEMM_ENTRIES)
         flops = gemm_flops_per_step(wl) * nrep
         ach = flops / (g_ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_mfma_kernel (Dense + implicit-GEMM Conv2D, all launches of a step)",
+        roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel (+ splitk_reduce): every Dense and "
+                          "implicit-GEMM Conv2D launch of a step",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep}
-        c_ms = kt.total_ms("ctc_loss_fwd")[0] + kt.total_ms("ctc_loss_bwd")[0]
+                "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep,
+                "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_floor_us": 1e3 * kt.floor_ms,
+                "flops_per_step": gemm_flops_per_step(wl)}
+        a_ms, a_calls = kt.total_ms(ATTN_ENTRIES)
+        aa = attention_flops_per_step(wl) * nrep / (a_ms * 1e-3) / 1e12
+        attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_dq/dkv_mfma_kernel (+ delta)", "bound": "mfma",
+                     "achieved": aa, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": aa / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms_per_step": a_ms / nrep,
+                     "launches_per_step": a_calls // nrep}
+        c_ms, _ = kt.total_ms(CTC_ENTRIES)
         cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
         ctc_roof = {"kernel": "ctc_prep + ctc_lattice + ctc_grad", "bound": "hbm", "achieved": cb,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS, "traffic": None,
-                    "ms_per_step": c_ms / nrep}
+                    "ms_per_step": c_ms / nrep, "bytes_per_step": ctc_bytes(wl)}
 
     if rank == 0:
         audio_s = wl["B"] * wl["T"] * FRAME_SHIFT_S * world * args.steps
@@ -227,7 +285,7 @@ def main():
                        "frames": wl["T"], "fbank_dim": wl["feat"], "classes": V, "parallelism": "dp%d" % world,
                        "hip_graph": bool(solver.hparams.enable_tf_function), "dropout": wl["rate"]},
             "final_loss": final_loss,
-            "roofline": roof, "roofline_ctc": ctc_roof,
+            "roofline": roof, "roofline_attention": attn_roof, "roofline_ctc": ctc_roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, model, mc)

@@ -23,6 +23,18 @@ def main(path, steps):
     for n, cnt, s, a, mn, mx in rows:
         print("%-110s %8d %12.3f %10.2f %10.2f %10.2f %6.2f" % (short(n), cnt, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3,
                                                                   100.0 * s / tot))
+    # kernel families as bench.py groups them (C-ABI entry points)
+    fams = [("GEMM core (gemm_mfma*, splitk_reduce*)", ("gemm_mfma", "splitk_reduce")),
+            ("attention (mha_*)", ("mha_",)),
+            ("CTC (ctc_*)", ("ctc_",))]
+    print()
+    print("%-50s %10s %14s %12s" % ("family", "calls/step", "ms per step", "avg_us"))
+    for label, keys in fams:
+        sel = [r for r in rows if any(k in r[0] for k in keys)]
+        cnt = sum(r[1] for r in sel)
+        t = sum(r[2] for r in sel)
+        if cnt:
+            print("%-50s %10.1f %14.3f %12.2f" % (label, cnt / steps, t / 1e6 / steps, t / 1e3 / cnt))
 
 
 if __name__ == "__main__":
