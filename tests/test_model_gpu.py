@@ -138,6 +138,40 @@ def test_graph_replay_matches_eager_steps(precision):
     assert worst <= (1e-4 if precision == "fp32" else 2e-2), worst
 
 
+def test_data_parallel_step_structure_on_one_gpu():
+    """The data-parallel step (forward/backward graph -> gradient exchange -> update graph with the
+    1/world_size factor) with the exchange replaced by "the other rank had the same gradients":
+    it must reproduce the single-process trajectory, eagerly and under graph replay."""
+    from athena_amd import BaseSolver, HorovodSolver, WarmUpAdam
+    from tests.modelutil import model_config
+    case = dict(TINY, mc=model_config(32, 16, 4, 2, 1, 64, rate=0.1))
+    opt_cfg = dict(d_model=32, warmup_steps=3, k=0.05, decay_steps=100000, decay_rate=1.0)
+    out = {}
+    for mode in ("single", "dp_eager", "dp_graph"):
+        model, samples, _ = build(case, "fp32")
+        opt = WarmUpAdam(dict(opt_cfg))
+        cfg = {"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": mode == "dp_graph"}
+        if mode == "single":
+            solver = BaseSolver(model, opt, config=cfg)
+        else:
+            solver = HorovodSolver(model, opt, config=cfg)
+            solver.world_size = 2
+
+            def fake_exchange(st=model.store):
+                st.grads.mul_(2.0)              # sum over two ranks holding the same gradients
+                return 0.5
+            solver._reduce_gradients = fake_exchange
+        ds = model.prepare_samples(samples)
+        losses = [float(solver.train_step(ds)[0]) for _ in range(4)]
+        out[mode] = (losses, {k: v.clone() for k, v in model.store.state_dict().items()})
+    for mode in ("dp_eager", "dp_graph"):
+        for a, b in zip(out["single"][0], out[mode][0]):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (mode, out["single"][0], out[mode][0])
+        worst = max(rel_err(out[mode][1][k], out["single"][1][k].double().cpu()) for k in out[mode][1]
+                    if not k.endswith(ZERO_GRAD))
+        assert worst <= 1e-4, (mode, worst)
+
+
 @pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
 def test_bf16_logits_close_to_fp32_oracle(case):
     model, samples, ocfg = build(case, "bf16")
