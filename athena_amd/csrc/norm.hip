@@ -221,18 +221,27 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __r
 }
 
 #define LNV_ROWS_PER_BLOCK 32
-template <typename T>
+// sum over the G lanes of a group, G a compile-time power of two (the shuffles unroll)
+template <int G>
+__device__ __forceinline__ float group_sum_c(float v) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd,
                                                                     const float* __restrict__ gamma, int rows, int d,
-                                                                    int G, uint32_t thresh, float dscale,
+                                                                    uint32_t thresh, float dscale,
                                                                     const uint64_t* rng_state, uint32_t site,
                                                                     int accumulate_da, T* __restrict__ da,
                                                                     T* __restrict__ db, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta) {
-    __shared__ float red[2][512];
-    const int rpp = 256 / G;                         // rows per pass of the block
+                                                                    float* __restrict__ dbeta,
+                                                                    float* __restrict__ slabs) {
+    __shared__ float red[4][2][512];                 // [wave][dgamma | dbeta][column]
+    constexpr int rpp = 256 / G;                     // rows per pass of the block
     const int gl = threadIdx.x % G, gi = threadIdx.x / G;
     const bool col_ok = gl * 8 < d;
     const int c0 = col_ok ? gl * 8 : 0;
@@ -242,18 +251,18 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
     Vec8<float>::load(gamma + c0, g);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
-    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&red[0][0])[i] = 0.f;
-    __syncthreads();
     const int r0 = blockIdx.x * LNV_ROWS_PER_BLOCK;
     const int r1 = min(rows, r0 + LNV_ROWS_PER_BLOCK);
-    // two row passes per trip, all four loads issued before any arithmetic
-    for (int rb = r0; rb < r1; rb += 2 * rpp) {
-        int rowv[2];
-        bool livev[2];
-        long basev[2];
-        float dyv[2][8], x[2][8], muv[2], rsv[2];
+    // four row passes per trip, all loads issued before any arithmetic (a workgroup per CU has
+    // to keep enough bytes in flight on its own)
+    constexpr int NU = 4;
+    for (int rb = r0; rb < r1; rb += NU * rpp) {
+        int rowv[NU];
+        bool livev[NU];
+        long basev[NU];
+        float dyv[NU][8], x[NU][8], muv[NU], rsv[NU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             rowv[u] = rb + u * rpp + gi;
             livev[u] = rowv[u] < r1 && col_ok;
             const int rc = rowv[u] < r1 ? rowv[u] : r1 - 1;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
             rsv[u] = rstd[rc];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const bool live = livev[u];
             const long base = basev[u];
             const float mu = muv[u], rs = rsv[u];
@@ -280,8 +289,8 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
                 c1 += gy[i];
                 c2 += gy[i] * x[u][i];
             }
-            c1 = group_sum(c1, G) / d;
-            c2 = group_sum(c2, G) / d;
+            c1 = group_sum_c<G>(c1) / d;
+            c2 = group_sum_c<G>(c2) / d;
             if (live) {
                 float dz[8];
 #pragma unroll
@@ -305,18 +314,63 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
             }
         }
     }
-    // fold the row groups of the block in LDS, then one atomic per column per block
-    if (col_ok) {
+    // fold the row groups: inside a wave by shuffles (lanes with equal gl), across the four waves in LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            atomicAdd(&red[0][c0 + i], pg[i]);
-            atomicAdd(&red[1][c0 + i], pb[i]);
+    for (int i = 0; i < 8; ++i) {
+        float a = pg[i], b = pb[i];
+#pragma unroll
+        for (int o = G; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if (lane < G && col_ok) {
+            red[w][0][c0 + i] = a;
+            red[w][1][c0 + i] = b;
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) {
-        atomicAdd(dgamma + c, red[0][c]);
-        atomicAdd(dbeta + c, red[1][c]);
+    // G > 64 never happens (d <= 512); for G == 64 each wave holds one row group
+    if (slabs) {
+        // one slab [2][d] per workgroup, summed by ln_fold_kernel: no same-address atomic chains
+        float* dst = slabs + (long)blockIdx.x * 2 * d;
+        for (int c = threadIdx.x; c < 2 * d; c += 256) {
+            const int which = c >= d, col = c - which * d;
+            dst[c] = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const int which = c >= d, col = c - which * d;
+        const float t = (red[0][which][col] + red[1][which][col]) + (red[2][which][col] + red[3][which][col]);
+        atomicAdd((which ? dbeta : dgamma) + col, t);
+    }
+}
+
+// dgamma / dbeta = column sums of the slabs.  Workgroup = 16 entries x 16 parts: part p adds slabs
+// p, p + 16, ... (four loads in flight), the 16 partial sums meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ slabs, int nblk, int d,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[16][17];
+    const int part = threadIdx.x >> 4, le = threadIdx.x & 15;
+    const int e = blockIdx.x * 16 + le;              // entry of the [2][d] slab
+    const long stride = 2L * d;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < 2 * d) {
+        int b = part;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += slabs[(long)b * stride + e];
+            a1 += slabs[(long)(b + 16) * stride + e];
+            a2 += slabs[(long)(b + 32) * stride + e];
+            a3 += slabs[(long)(b + 48) * stride + e];
+        }
+        for (; b < nblk; b += 16) a0 += slabs[(long)b * stride + e];
+    }
+    red[part][le] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && e < 2 * d) {
+        float t = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < 16; ++p2) t += red[p2][le];
+        if (e < d) dgamma[e] = t;
+        else dbeta[e - d] = t;
     }
 }
 
@@ -373,13 +427,42 @@ extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const floa
 template <typename T>
 static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* gamma,
                          int rows, int d, uint32_t th, float ds, const uint64_t* rng_state, uint32_t site,
-                         int acc, void* da, void* db, float* dgamma, float* dbeta, hipStream_t stream) {
+                         int acc, void* da, void* db, float* dgamma, float* dbeta, float* slabs,
+                         hipStream_t stream) {
     if (ln_vec_ok(d, {dy, z, gamma, da, db})) {
-        dim3 vgrid((rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK);
-        hipLaunchKernelGGL((add_layernorm_bwd_vec_kernel<T>), vgrid, dim3(256), 0, stream, (const T*)dy, (const T*)z, mean,
-                           rstd, gamma, rows, d, ln_group(d), th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, dbeta);
+        const int nblk = (rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK;
+        if (!slabs) {
+            ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, stream) == hipSuccess &&
+                               hipMemsetAsync(dbeta, 0, sizeof(float) * d, stream) == hipSuccess,
+                           ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
+        }
+#define LNV_BWD(GG)                                                                                                  \
+    hipLaunchKernelGGL((add_layernorm_bwd_vec_kernel<T, GG>), dim3(nblk), dim3(256), 0, stream, (const T*)dy,      \
+                       (const T*)z, mean, rstd, gamma, rows, d, th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, \
+                       dbeta, slabs)
+        switch (ln_group(d)) {
+            case 1: LNV_BWD(1); break;
+            case 2: LNV_BWD(2); break;
+            case 4: LNV_BWD(4); break;
+            case 8: LNV_BWD(8); break;
+            case 16: LNV_BWD(16); break;
+            case 32: LNV_BWD(32); break;
+            default: LNV_BWD(64); break;
+        }
+#undef LNV_BWD
+        if (slabs)
+            hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, stream, (const float*)slabs, nblk, d,
+                               dgamma, dbeta);
         ATHENA_CHECK_LAUNCH("add_layernorm_bwd");
         return ATHENA_OK;
+    }
+    if (dbeta == dgamma + d) {       // adjacent (the usual parameter layout): one fill
+        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * d, stream) == hipSuccess, ATHENA_E_LAUNCH,
+                       "add_layernorm_bwd: memset failed");
+    } else {
+        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, stream) == hipSuccess &&
+                           hipMemsetAsync(dbeta, 0, sizeof(float) * d, stream) == hipSuccess,
+                       ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
     }
     dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK);
 #define LN_BWD_CASE(V)                                                                                          \
@@ -394,28 +477,30 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
     return ATHENA_OK;
 }
 
+extern "C" int64_t athena_add_layernorm_bwd_workspace_bytes(int rows, int d) {
+    if (rows <= 0 || d <= 0) return 0;
+    return (int64_t)sizeof(float) * ((rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK) * 2 * d;
+}
+
 extern "C" int athena_add_layernorm_bwd(const void* dy, const void* z, const float* mean, const float* rstd,
                                         const float* gamma, int rows, int d, int dtype, float drop_p,
                                         const uint64_t* rng_state, uint32_t rng_site, int accumulate_da, void* da,
-                                        void* db, float* dgamma, float* dbeta, athena_stream_t stream) {
+                                        void* db, float* dgamma, float* dbeta, void* workspace,
+                                        int64_t workspace_bytes, athena_stream_t stream) {
     ATHENA_REQUIRE(dy && z && mean && rstd && gamma && da && dgamma && dbeta, ATHENA_E_SHAPE, "add_layernorm_bwd: null operand");
     ATHENA_REQUIRE(rows > 0 && d > 0 && d <= 2048, ATHENA_E_SHAPE, "add_layernorm_bwd: bad shape rows=%d d=%d (d <= 2048)", rows, d);
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && db), ATHENA_E_SHAPE, "add_layernorm_bwd: dropout args");
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     hipStream_t s = (hipStream_t)stream;
-    if (dbeta == dgamma + d) {       // adjacent (the usual parameter layout): one fill
-        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * d, s) == hipSuccess, ATHENA_E_LAUNCH,
-                       "add_layernorm_bwd: memset failed");
-    } else {
-        ATHENA_REQUIRE(hipMemsetAsync(dgamma, 0, sizeof(float) * d, s) == hipSuccess &&
-                           hipMemsetAsync(dbeta, 0, sizeof(float) * d, s) == hipSuccess,
-                       ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
-    }
+    float* slabs = nullptr;
+    if (workspace && athena_aligned16(workspace) &&
+        workspace_bytes >= athena_add_layernorm_bwd_workspace_bytes(rows, d))
+        slabs = (float*)workspace;
     if (dtype == ATHENA_BF16)
-        return launch_ln_bwd<bf16_t>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, s);
+        return launch_ln_bwd<bf16_t>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, slabs, s);
     if (dtype == ATHENA_F32)
-        return launch_ln_bwd<float>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, s);
+        return launch_ln_bwd<float>(dy, z, mean, rstd, gamma, rows, d, th, ds, rng_state, rng_site, accumulate_da, da, db, dgamma, dbeta, slabs, s);
     ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "add_layernorm_bwd: dtype");
 }
 
