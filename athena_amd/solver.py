@@ -178,7 +178,7 @@ class _GraphStep:
         self.inputs = {k: v.clone() for k, v in samples.items()}
         metrics_objs = solver._metric_objects()
         before = [len(m._pending) for m in metrics_objs]
-        split = solver.world_size > 1
+        split = solver.world_size > 1 or getattr(solver, "_force_exchange", False)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -242,6 +242,9 @@ class HorovodSolver(BaseSolver):
         st = model.store
         self._buckets = bucket_ranges(st.seg_offsets.tolist(), st.n_train, int(self.BUCKET_MB * (1 << 20) / 4))
         self._broadcast_done = False
+        # ATHENA_FORCE_DP=1 runs the exchange (and the two-graph step) even with one rank: a way to
+        # exercise the RCCL path on a single GPU
+        self._force_exchange = os.environ.get("ATHENA_FORCE_DP", "0") == "1" and dist.is_initialized()
 
     @staticmethod
     def initialize_devices(solver_gpus=None):
@@ -268,7 +271,7 @@ class HorovodSolver(BaseSolver):
     def _reduce_gradients(self):
         """Sum the flat gradient buffer over ranks bucket by bucket; the 1/world_size of the
         average is folded into the optimizer kernel."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self._force_exchange:
             return 1.0
         g = self.model.store.grads
         works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in self._buckets]

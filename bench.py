@@ -47,8 +47,7 @@ def build(wl, precision, seed):
     model = MtlTransformerCtc(DataDescriptions(wl["vocab"], wl["feat"]), mc, precision=precision, seed=seed)
     opt = WarmUpAdam(dict(wl["opt"]))
     cfg = {"clip_norm": wl["clip_norm"], "log_interval": 10 ** 9, "enable_tf_function": True}
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    solver = (HorovodSolver if world > 1 else BaseSolver)(model, opt, config=cfg)
+    solver = (HorovodSolver if dist.is_initialized() else BaseSolver)(model, opt, config=cfg)
     return model, opt, solver, mc
 
 
@@ -204,8 +203,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl")
+    if world > 1 or os.environ.get("ATHENA_FORCE_DP", "0") == "1":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     wl = WORKLOADS[args.workload]
 
     from oracle import model as om      # synthetic batch generator only (inputs, not the measured path)
@@ -215,12 +214,12 @@ def main():
     V = wl["vocab"] + 1
     samples = om.make_samples(wl["B"], wl["T"], wl["feat"], V, wl["U"], seed=1 + rank, full_length=True)
     ds = model.prepare_samples(samples)          # resident in HBM before the timed region
-    if world > 1:
+    if dist.is_initialized():
         solver.broadcast_variables()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -290,7 +289,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, model, mc)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
