@@ -70,8 +70,13 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, src, src_mask=None, training=None):
         output = src
-        for layer in self.layers:
+        n = len(self.layers)
+        store = getattr(self.layers[0], "store", None) if n else None
+        for i, layer in enumerate(self.layers):
             output = layer(output, src_mask=src_mask, training=training)
+            # cut points for a pipelined backward pass: after every third of the stack
+            if store is not None and store.collect_cuts and n >= 3 and i + 1 < n and (i + 1) % ((n + 2) // 3) == 0:
+                store.cuts.append(("encoder.%d" % (i + 1), output))
         return output
 
 

@@ -127,10 +127,14 @@ class SpeechTransformer(BaseModel):
         y0 = insert_sos_in_labels(samples["output"], self.sos)
         x = self.x_net(x0, training=training)
         y = self.y_net(y0, training=training)
+        if self.store.collect_cuts:
+            self.store.cuts = [("y_net", y)]
         input_length = self.compute_logit_length(samples)
         input_mask, output_mask = create_multihead_mask(x, input_length, y0)
         y, encoder_output = self.transformer(x, y, input_mask, output_mask, input_mask, training=training,
                                              return_encoder_output=True)
+        if self.store.collect_cuts:
+            self.store.cuts.append(("memory", encoder_output))
         y = self._project(self.final_layer, y)
         if self.hparams.return_encoder_output:
             return y, encoder_output

@@ -59,6 +59,10 @@ class ParamStore:
         self.by_name = {}
         self.finalized = False
         self.shadows_dirty = True
+        # activations at which the backward pass may be cut into pieces (filled during a forward pass
+        # when ``collect_cuts`` is set; see solver._PipelinedGraphStep): list of (tag, tensor)
+        self.collect_cuts = False
+        self.cuts = []
         self._site = 0
 
     # ---- registration (before finalize) -------------------------------------------------

@@ -109,8 +109,11 @@ class BaseSolver:
             self._graphs[key] = False
             return self._eager_step(samples)
         if state is False:
-            state = self._graphs[key] = _GraphStep(self, samples)
+            state = self._graphs[key] = self._record(samples)
         return state.run(samples)
+
+    def _record(self, samples):
+        return _GraphStep(self, samples)
 
     def _graphable(self, samples):
         if not getattr(self.hparams, "enable_tf_function", False) or not isinstance(samples, dict):
@@ -160,6 +163,11 @@ class BaseSolver:
         return mean_loss, metrics
 
 
+# other host threads (the RCCL watchdog polling its events) keep making HIP calls while a step is
+# being recorded: only calls of the recording thread itself may invalidate the capture
+_CAPTURE_MODE = "thread_local"
+
+
 def _shape_key(samples):
     return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(samples.items()))
 
@@ -181,14 +189,14 @@ class _GraphStep:
         split = solver.world_size > 1 or getattr(solver, "_force_exchange", False)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.loss, self.metrics = solver._forward_backward(self.inputs)
             if not split:
                 solver._update(1.0)
         self.update_graph = None
         if split:
             self.update_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.update_graph, pool=self.graph.pool()):
+            with torch.cuda.graph(self.update_graph, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
                 solver._update(1.0 / solver.world_size)
         # the deferred scorers queued while recording become templates
         self.templates = []
@@ -208,6 +216,119 @@ class _GraphStep:
             for t in items:
                 m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
         return self.loss, self.metrics
+
+
+class _PipelinedGraphStep:
+    """The data-parallel step as a chain of HIP graphs with the gradient exchange in between.
+
+    The backward pass is cut at a few activations (decoder | encoder thirds | front end).  Each piece
+    is its own graph; when a piece has been replayed, the gradients of the parameters it covers are
+    final -- they form one contiguous range of the flat gradient buffer -- and their all-reduce is
+    started on RCCL's stream while the next piece is replayed.  Only the exchange of the last range
+    (front end + first encoder layers) is not hidden behind compute.  The update graph (clip + Adam
+    with 1/world_size) runs after all exchanges."""
+
+    def __init__(self, solver, samples):
+        self.solver = solver
+        store = solver.model.store
+        self.inputs = {k: v.clone() for k, v in samples.items()}
+        metrics_objs = solver._metric_objects()
+        before = [len(m._pending) for m in metrics_objs]
+        torch.cuda.synchronize()
+        self.graphs = []
+        g0 = torch.cuda.CUDAGraph()
+        store.collect_cuts = True
+        try:
+            with torch.cuda.graph(g0, capture_error_mode=_CAPTURE_MODE):
+                outputs = solver.model(self.inputs, training=True)
+                self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
+                total = sum(list(self.loss.values())) if isinstance(self.loss, dict) else self.loss
+                cuts = dict(store.cuts)
+                order = [t for t, _ in store.cuts]
+                enc_cuts = [t for t in order if t.startswith("encoder.")]          # forward order
+                g_mem, g_y = torch.autograd.grad(total, [cuts["memory"], cuts["y_net"]], retain_graph=True)
+        finally:
+            store.collect_cuts = False
+            store.cuts = []
+        self.graphs.append(g0)
+        self.ranges = _piece_ranges(store, [int(t.split(".")[1]) for t in enc_cuts])
+        # encoder pieces, from the top of the stack down
+        up, g_up = cuts["memory"], g_mem
+        for tag in reversed(enc_cuts):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+                (g_dn,) = torch.autograd.grad([up], [cuts[tag]], [g_up], retain_graph=True)
+            self.graphs.append(g)
+            up, g_up = cuts[tag], g_dn
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+            torch.autograd.backward([up, cuts["y_net"]], [g_up, g_y])
+        self.graphs.append(g)
+        assert len(self.graphs) == len(self.ranges)
+        self.update_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.update_graph, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+            solver._update(1.0 / max(solver.world_size, 1))
+        self._keep = (cuts, g_mem, g_y, up, g_up)          # the graphs' buffers must outlive them
+        self.templates = []
+        for m, n in zip(metrics_objs, before):
+            self.templates.append((m, m._pending[n:]))
+            del m._pending[n:]
+
+    def run(self, samples):
+        from .metrics import _Deferred
+        for k, v in self.inputs.items():
+            v.copy_(samples[k], non_blocking=True)
+        grads = self.solver.model.store.grads
+        step = max(int(self.solver.BUCKET_MB * (1 << 20) / 4), 1)
+        works = []
+        for g, (a, b) in zip(self.graphs, self.ranges):
+            g.replay()
+            for lo in range(a, b, step):
+                works.append(self.solver._exchange_async(grads[lo:min(lo + step, b)]))
+        for w in works:
+            if w is not None:
+                w.wait()
+        self.update_graph.replay()
+        for m, items in self.templates:
+            for t in items:
+                m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
+        return self.loss, self.metrics
+
+
+def _piece_ranges(store, enc_cut_layers):
+    """Ranges of the flat gradient buffer that are final after each backward piece, in replay order:
+    [decoder + heads], [encoder layers >= last cut], ..., [front end, y_net, first encoder layers].
+    Relies on the registration order front end < encoder.0 < ... < decoder < heads; raises if the
+    parameter layout does not have that shape."""
+    n = store.n_train
+    first = {}
+    for s in store.train_slots:
+        name = s.name
+        if name.startswith("encoder."):
+            key = int(name.split(".")[1])
+        elif name.startswith(("x_net.", "y_net.")):
+            key = -1
+        else:
+            key = 1 << 30
+        first[key] = min(first.get(key, n), s.offset)
+    bounds = [first.get(1 << 30, n)]
+    for layer in sorted(enc_cut_layers, reverse=True):
+        bounds.append(first[layer])
+    bounds.append(0)
+    # every slot must fall into the range its piece claims
+    for s in store.train_slots:
+        name = s.name
+        if name.startswith("encoder."):
+            li = int(name.split(".")[1])
+            piece = 1 + sum(1 for c in sorted(enc_cut_layers, reverse=True) if li < c)
+        elif name.startswith(("x_net.", "y_net.")):
+            piece = len(bounds) - 1
+        else:
+            piece = 0
+        hi = n if piece == 0 else bounds[piece - 1]
+        if not (bounds[piece] <= s.offset < hi):
+            raise RuntimeError("parameter layout does not allow a pipelined gradient exchange (%s)" % name)
+    return [(bounds[i], n if i == 0 else bounds[i - 1]) for i in range(len(bounds))]
 
 
 def bucket_ranges(seg_offsets, n_total, bucket_elems):
@@ -268,16 +389,31 @@ class HorovodSolver(BaseSolver):
             st.shadows_dirty = True
         self._broadcast_done = True
 
+    def _exchange_async(self, t):
+        """Start the sum of a slice of the flat gradient buffer over the ranks; returns the handle."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
     def _reduce_gradients(self):
         """Sum the flat gradient buffer over ranks bucket by bucket; the 1/world_size of the
         average is folded into the optimizer kernel."""
         if self.world_size == 1 and not self._force_exchange:
             return 1.0
         g = self.model.store.grads
-        works = [dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in self._buckets]
+        works = [self._exchange_async(g[a:b]) for a, b in self._buckets]
         for w in works:
-            w.wait()
+            if w is not None:
+                w.wait()
         return 1.0 / self.world_size
+
+    def _record(self, samples):
+        # Off by default: on one MI355X every extra graph boundary costs ~0.27 ms (0.8 ms for the four
+        # pieces of a 12-layer encoder), about what hiding an 84 MB exchange over 8 GPUs can win back.
+        if (self.world_size > 1 or self._force_exchange) and os.environ.get("ATHENA_DP_PIPELINE", "0") == "1":
+            try:
+                return _PipelinedGraphStep(self, samples)
+            except RuntimeError as e:          # unusual parameter layout: exchange after the whole backward pass
+                logging.warning("pipelined gradient exchange disabled: %s", e)
+        return _GraphStep(self, samples)
 
     def train(self, dataset, total_batches=-1):
         """Update the model in 1 epoch (solver.py:176-197)."""

@@ -5,6 +5,7 @@ its largest element), parameters after optimizer steps within 1e-5.  bf16 mode: 
 1e-2 absolute of the fp32 oracle.
 """
 import copy
+import os
 
 import pytest
 import torch
@@ -144,27 +145,34 @@ def test_data_parallel_step_structure_on_one_gpu():
     it must reproduce the single-process trajectory, eagerly and under graph replay."""
     from athena_amd import BaseSolver, HorovodSolver, WarmUpAdam
     from tests.modelutil import model_config
-    case = dict(TINY, mc=model_config(32, 16, 4, 2, 1, 64, rate=0.1))
+    case = dict(TINY, mc=model_config(32, 16, 4, 3, 1, 64, rate=0.1))     # 3 encoder layers: two encoder cuts
     opt_cfg = dict(d_model=32, warmup_steps=3, k=0.05, decay_steps=100000, decay_rate=1.0)
     out = {}
-    for mode in ("single", "dp_eager", "dp_graph"):
+    for mode in ("single", "dp_eager", "dp_graph", "dp_graph_unpipelined"):
+        os.environ["ATHENA_DP_PIPELINE"] = "0" if mode == "dp_graph_unpipelined" else "1"
         model, samples, _ = build(case, "fp32")
         opt = WarmUpAdam(dict(opt_cfg))
-        cfg = {"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": mode == "dp_graph"}
+        cfg = {"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": mode.startswith("dp_graph")}
         if mode == "single":
             solver = BaseSolver(model, opt, config=cfg)
         else:
             solver = HorovodSolver(model, opt, config=cfg)
             solver.world_size = 2
 
-            def fake_exchange(st=model.store):
-                st.grads.mul_(2.0)              # sum over two ranks holding the same gradients
-                return 0.5
-            solver._reduce_gradients = fake_exchange
+            def fake_exchange(t):
+                t.mul_(2.0)                     # sum over two ranks holding the same gradients
+                return None
+            solver._exchange_async = fake_exchange
         ds = model.prepare_samples(samples)
         losses = [float(solver.train_step(ds)[0]) for _ in range(4)]
         out[mode] = (losses, {k: v.clone() for k, v in model.store.state_dict().items()})
-    for mode in ("dp_eager", "dp_graph"):
+        if mode == "dp_graph":
+            from athena_amd.solver import _PipelinedGraphStep
+            assert any(isinstance(v, _PipelinedGraphStep) for v in solver._graphs.values())
+            st = [v for v in solver._graphs.values() if isinstance(v, _PipelinedGraphStep)][0]
+            assert st.ranges[0][1] == model.store.n_train and st.ranges[-1][0] == 0
+    os.environ.pop("ATHENA_DP_PIPELINE", None)
+    for mode in ("dp_eager", "dp_graph", "dp_graph_unpipelined"):
         for a, b in zip(out["single"][0], out[mode][0]):
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (mode, out["single"][0], out[mode][0])
         worst = max(rel_err(out[mode][1][k], out["single"][1][k].double().cpu()) for k in out[mode][1]
