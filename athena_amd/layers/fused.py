@@ -291,7 +291,9 @@ class MultiHeadAttentionFn(torch.autograd.Function):
 class DenseFn(torch.autograd.Function):
     """y = x @ kernel + bias with an fp32 output whose rows are padded to a multiple of 8 columns
     (the vocabulary projections: speech_transformer.py:130,151 and mtl_seq2seq.py:62,83).
-    Returns the padded tensor [B, T, Np]; the caller slices [..., :N]."""
+    Returns the [B, T, N] view of the padded buffer [B, T, Np].  The loss kernels hand back a
+    gradient that is such a view too; the backward pass then uses its buffer in place instead of
+    copying it into a fresh padded tensor."""
 
     @staticmethod
     def forward(ctx, x, dense, kernel, bias):
@@ -303,14 +305,24 @@ class DenseFn(torch.autograd.Function):
         if Np != N:
             out[:, N:].zero_()
         ctx.dense, ctx.x2, ctx.shape = dense, x2, (B, T, K, N, Np)
-        return out.view(B, T, Np)
+        return out.view(B, T, Np)[..., :N]
 
     @staticmethod
     def backward(ctx, dy):
         dense, x2 = ctx.dense, ctx.x2
         B, T, K, N, Np = ctx.shape
         M = B * T
-        dy = dy.contiguous().view(M, Np)
+        if Np != N and dy.stride() == (T * Np, Np, 1) and dy.storage_offset() % 4 == 0 and \
+                dy.untyped_storage().nbytes() >= (dy.storage_offset() + M * Np) * dy.element_size():
+            # a view of a padded buffer (what the loss kernels return): take the buffer itself
+            dy = dy.as_strided((M, Np), (Np, 1))
+            dy[:, N:].zero_()
+        elif Np != N:
+            full = torch.zeros((M, Np), dtype=dy.dtype, device=dy.device)
+            full[:, :N] = dy.reshape(M, N)
+            dy = full
+        else:
+            dy = dy.contiguous().view(M, Np)
         if x2.dtype != dy.dtype:
             g = torch.empty((M, Np), dtype=x2.dtype, device=dy.device)
             ops.cast(dy, g)

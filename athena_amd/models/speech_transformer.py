@@ -143,8 +143,7 @@ class SpeechTransformer(BaseModel):
     @staticmethod
     def _project(dense, h):
         """Dense(V): fp32 logits [B, T, V] as a view of rows padded to a multiple of 8 columns."""
-        out = DenseFn.apply(h, dense, dense.kernel, dense.bias)
-        return out[..., :dense.out_features]
+        return DenseFn.apply(h, dense, dense.kernel, dense.bias)
 
     def compute_logit_length(self, samples):
         """ceil(ceil(len/2)/2) (speech_transformer.py:156-162)."""
