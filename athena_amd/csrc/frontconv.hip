@@ -244,9 +244,10 @@ extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, c
 // partial[blk][t][c] (t < 9: sum a g; t == 9: sum g), fp32, one slab per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restrict__ in, const T* __restrict__ g,
-                                                            int B, int H, int W, int C, int Ho, int Wo, int ph, int pw,
+                                                            const T* __restrict__ act, int B, int H, int W, int C,
+                                                            int Ho, int Wo, int ph, int pw,
                                                             float* __restrict__ partial) {
-    extern __shared__ float red[];                   // [(FC_K + 1)][C]
+    extern __shared__ float red[];                   // [4 waves][(FC_K + 1)][C] (C <= 512), else [(FC_K + 1)][C]
     const int cpr = C / 8;
     const int chunk = threadIdx.x % cpr, slot = threadIdx.x / cpr, slots = 256 / cpr;
     const int c0 = chunk * 8;
@@ -255,8 +256,11 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
     for (int t = 0; t <= FC_K; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-    for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
-    __syncthreads();
+    const bool planes = cpr <= 64;                   // fold by shuffles + one LDS plane per wave
+    if (!planes) {
+        for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
+        __syncthreads();
+    }
     const long npix = (long)B * Ho * Wo;
     for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
         const int q = pix / Wo, wo = pix - q * Wo;
@@ -267,11 +271,23 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
             const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + (long)pix * C + c0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) gv[i] = (float)h[i];
+            if (act) {       // g is the gradient w.r.t. the relu6 output: apply the gate read off the activation
+                const bf16x8_t y = *(const bf16x8_t*)((const bf16_t*)act + (long)pix * C + c0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gv[i] = ((float)y[i] > 0.f && (float)y[i] < 6.f) ? gv[i] : 0.f;
+            }
         } else {
             const float* gp = (const float*)g + (long)pix * C + c0;
             const float4 h0 = *(const float4*)gp, h1 = *(const float4*)(gp + 4);
             gv[0] = h0.x; gv[1] = h0.y; gv[2] = h0.z; gv[3] = h0.w;
             gv[4] = h1.x; gv[5] = h1.y; gv[6] = h1.z; gv[7] = h1.w;
+            if (act) {
+                const float* yp = (const float*)act + (long)pix * C + c0;
+                const float4 y0 = *(const float4*)yp, y1 = *(const float4*)(yp + 4);
+                const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gv[i] = (y[i] > 0.f && y[i] < 6.f) ? gv[i] : 0.f;
+            }
         }
 #pragma unroll
         for (int t = 0; t < FC_K; ++t)
@@ -280,13 +296,30 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[FC_K][i] += gv[i];
     }
-    // fold the pixel slots of the workgroup in LDS, then store the slab
+    // fold the pixel slots of the workgroup, then store the slab
+    float* dst = partial + (long)blockIdx.x * (FC_K + 1) * C;
+    if (planes) {
+        // lanes with equal chunk inside a wave by shuffles, then the four waves through LDS
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int nent = (FC_K + 1) * C;
+#pragma unroll
+        for (int t = 0; t <= FC_K; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = acc[t][i];
+                for (int o = cpr; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (lane < cpr) red[w * nent + t * C + c0 + i] = v;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nent; i += 256)
+            dst[i] = (red[i] + red[nent + i]) + (red[2 * nent + i] + red[3 * nent + i]);
+        return;
+    }
 #pragma unroll
     for (int t = 0; t <= FC_K; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(&red[t * C + c0 + i], acc[t][i]);
     __syncthreads();
-    float* dst = partial + (long)blockIdx.x * (FC_K + 1) * C;
     for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) dst[i] = red[i];
 }
 
@@ -346,7 +379,8 @@ extern "C" int64_t athena_conv1_bn_bwd_workspace_bytes(int Cout) {
     return (int64_t)sizeof(float) * FC_BWD_BLOCKS * nent + (int64_t)sizeof(double) * nent;   // slabs + totals
 }
 
-extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const float* w_hwio, const double* moments,
+extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* relu6_out, const float* w_hwio,
+                                   const double* moments,
                                    const float* mean_rstd, const float* gamma, int B, int H, int W, int Cout,
                                    int dtype, void* workspace, int64_t workspace_bytes, float* dw_hwio, float* dgamma,
                                    float* dbeta, athena_stream_t stream) {
@@ -366,13 +400,14 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const float* 
     long blocks = (npix + slots - 1) / slots;
     if (blocks > FC_BWD_BLOCKS) blocks = FC_BWD_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
-    const size_t shm = sizeof(float) * (FC_K + 1) * Cout;
+    const size_t shm = sizeof(float) * (FC_K + 1) * Cout * (Cout / 8 <= 64 ? 4 : 1);
+    ATHENA_REQUIRE(!relu6_out || athena_aligned16(relu6_out), ATHENA_E_ALIGN, "athena_conv1_bn_bwd: relu6_out alignment");
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(fc_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const bf16_t*)g, B,
-                           H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
+        hipLaunchKernelGGL(fc_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const bf16_t*)g,
+                           (const bf16_t*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
     else
-        hipLaunchKernelGGL(fc_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const float*)g, B, H,
-                           W, Cout, Ho, Wo, ph, pw, (float*)workspace);
+        hipLaunchKernelGGL(fc_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const float*)g,
+                           (const float*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
     const int nent = (FC_K + 1) * Cout;
     double* tot = (double*)((char*)workspace + sizeof(float) * (size_t)FC_BWD_BLOCKS * nent);   // 8-byte aligned
     hipLaunchKernelGGL(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,

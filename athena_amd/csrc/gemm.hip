@@ -284,7 +284,7 @@ extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout,
     memset(&p, 0, sizeof(p));
     p.A = in;
     p.B = w;
-    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
+    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw, GM_BK / Wo, GM_BK % Wo};
     p.M = B * Ho * Wo;
     p.N = Cout;
     p.nseg = 9;
@@ -404,7 +404,7 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     memset(&p, 0, sizeof(p));
     p.A = in;
     p.B = dout;
-    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw};
+    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw, GM_BK / Wo, GM_BK % Wo};
     p.M = Cin;
     p.N = Cout;
     p.nseg = 1;

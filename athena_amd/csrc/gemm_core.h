@@ -133,6 +133,7 @@ struct ConvFwdRows {
     static constexpr bool kCanMiss = true;
     static constexpr bool kSegmented = true;
     int H, W, C, Ho, Wo, pad_h, pad_w;
+    int step_q, step_r;          // GM_BK / Wo and GM_BK % Wo (host side), for step() by one k-tile
     struct Row { int b, ho, wo; };
     __device__ __forceinline__ Row prep(int r) const {
         Row x;
@@ -146,11 +147,14 @@ struct ConvFwdRows {
         const int kh = seg / 3, kw = seg - kh * 3;
         const int h = 2 * x.ho - pad_h + kh, w = 2 * x.wo - pad_w + kw;
         if (h < 0 || h >= H || w < 0 || w >= W) return -1;
-        return (((long)x.b * H + h) * W + w) * C;
+        return (long)((x.b * H + h) * W + w) * C;     // pixel index fits 31 bits (checked on the host)
     }
-    __device__ __forceinline__ void step(Row& x, int d) const {
-        x.wo += d;
-        while (x.wo >= Wo) { x.wo -= Wo; ++x.ho; }
+    // advance by one k-tile (d == GM_BK rows): one conditional carry per coordinate instead of a
+    // division; the second loop only iterates when an image has fewer rows than the carry
+    __device__ __forceinline__ void step(Row& x, int) const {
+        x.wo += step_r;
+        x.ho += step_q;
+        if (x.wo >= Wo) { x.wo -= Wo; ++x.ho; }
         while (x.ho >= Ho) { x.ho -= Ho; ++x.b; }
     }
 };

@@ -428,11 +428,11 @@ class XNetFn(torch.autograd.Function):
         da1 = torch.empty_like(a1)
         w_hwio = net.conv2.shadow if c2.dtype == torch.bfloat16 else net.conv2.kernel
         if mom1 is not None:
-            # da1 comes out already masked by the relu6 gate read off a1; the weight, gamma and beta
-            # gradients of the fused first layer need only its tap sums
-            ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C, relu6_out=a1)
+            # the weight, gamma and beta gradients of the fused first layer need only tap sums of the
+            # gated gradient; the relu6 gate is read off a1 while da1 is streamed through
+            ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
             ops.conv1_bn_bwd(x0, da1, net.conv1.kernel, mom1, mr1, net.bn1.gamma, B, T, Fd, C, net.conv1.kernel.grad,
-                             net.bn1.gamma.grad, net.bn1.beta.grad)
+                             net.bn1.gamma.grad, net.bn1.beta.grad, relu6_out=a1)
         else:
             ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
             dc1 = torch.empty_like(c1)

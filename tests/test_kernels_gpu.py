@@ -336,6 +336,7 @@ def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
     out = torch.full((B, Ho, Wo, C), float("nan"), dtype=cd, device=dev())
     ops.conv1_bn_relu6_fwd(xd, wd, mr, None, gd, bd, 1e-3, False, B, H, W, C, out)
     assert_close(out, y_ref.detach(), 1e-5 if cd == torch.float32 else 8e-3, "fused forward")
+    out_train = out.clone()
     # the stored activation carries the exact gate
     gate_ref = ((y_ref > 0) & (y_ref < 6)).detach()
     o64 = out.double().cpu()
@@ -351,6 +352,11 @@ def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
     assert_close(db, beta.grad, 2e-5, "dbeta")
     assert_close(dg, gamma.grad, 5e-5, "dgamma")
     assert_close(dw, w.grad, 5e-5, "dw")
+    # the same with the gate applied inside: ungated gradient + the stored activation
+    dw2, dg2, db2 = torch.empty_like(dw), torch.empty_like(dg), torch.empty_like(db)
+    ops.conv1_bn_bwd(xd, to_cd(dy, cd), wd, mom, mr, gd, B, H, W, C, dw2, dg2, db2, relu6_out=out_train)
+    assert_close(db2, beta.grad, 2e-5 if cd == torch.float32 else 2e-2, "dbeta (gate inside)")
+    assert_close(dw2, w.grad, 5e-5 if cd == torch.float32 else 2e-2, "dw (gate inside)")
     # inference form: moving statistics
     mm = (torch.randn(C, generator=g) * 0.1).to(dev())
     mv = (torch.rand(C, generator=g) + 0.5).to(dev())
