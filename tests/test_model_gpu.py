@@ -39,7 +39,15 @@ def oracle_params(model, dtype=torch.float64):
     return p
 
 
-@pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
+# the layer dimensions of the recipes named as benchmark configurations, on short batches
+from tests.modelutil import model_config  # noqa: E402
+TIMIT_DIMS = dict(vocab=49, feat=40, mc=model_config(256, 256, 8, 9, 3, 1024, ls=0.1), B=2, T=96, U=7)
+AISHELL_DIMS = dict(vocab=4232, feat=80, mc=model_config(256, 256, 4, 3, 2, 1024, ls=0.1), B=2, T=120, U=9)
+LIBRI_DIMS = dict(vocab=5000, feat=80, mc=model_config(512, 512, 8, 2, 1, 2048, mtl_weight=0.3), B=1, T=200, U=12)
+
+
+@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS],
+                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims"])
 def test_fp32_forward_loss_backward(case):
     model, samples, ocfg = build(case, "fp32")
     p = oracle_params(model)
@@ -180,15 +188,22 @@ def test_data_parallel_step_structure_on_one_gpu():
         assert worst <= 1e-4, (mode, worst)
 
 
-@pytest.mark.parametrize("case", [TINY, SMALL], ids=["tiny", "small"])
+@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS],
+                         ids=["tiny", "small", "timit-dims", "aishell-dims"])
 def test_bf16_logits_close_to_fp32_oracle(case):
     model, samples, ocfg = build(case, "bf16")
     p = oracle_params(model, torch.float32)
     att_ref, ctc_ref, _ = om.forward(p, samples, ocfg, training=True)
     ds = model.prepare_samples(samples)
     att, ctc = model(ds, training=True)
-    assert float((att.float().cpu() - att_ref.detach()).abs().max()) <= BF16_LOGIT_TOL
-    assert float((ctc.float().cpu() - ctc_ref.detach()).abs().max()) <= BF16_LOGIT_TOL
+    ea = float((att.float().cpu() - att_ref.detach()).abs().max())
+    ec = float((ctc.float().cpu() - ctc_ref.detach()).abs().max())
+    print("bf16 logits: max abs error attention %.3e ctc %.3e (logit scale %.2f / %.2f)" %
+          (ea, ec, float(att_ref.abs().max()), float(ctc_ref.abs().max())))
+    # stated tolerance: 3e-2 absolute, or 1.2 % of the largest |logit| where the logits are larger
+    # (bf16 keeps 8 significant bits: a logit of 5 is stored to within 2e-2 at best)
+    assert ea <= max(BF16_LOGIT_TOL, 1.2e-2 * float(att_ref.abs().max())), ea
+    assert ec <= max(BF16_LOGIT_TOL, 1.2e-2 * float(ctc_ref.abs().max())), ec
     loss, _ = model.get_loss((att, ctc), ds, training=True)
     loss_ref = om.get_loss(att_ref, ctc_ref, samples, ocfg)[0]
     assert_close(loss, loss_ref.detach(), 2e-3, "bf16 loss")
