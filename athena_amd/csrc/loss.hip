@@ -15,6 +15,7 @@
 #include "common.h"
 
 #define CTC_LOGZERO (-1e30f)
+#define CTC_PF 8                // emission rows fetched ahead of the lattice recursion
 #define CTC_MAX_R 16            // lattice states per lane: supports 2U+1 <= 1024
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -137,6 +138,15 @@ __device__ __forceinline__ float lse2(float a, float b) {
     return m + __logf(__expf(a - m) + __expf(b - m));
 }
 
+// value held by the previous / next lane of the wave (``fill`` where there is none): a single DPP
+// move (wave_shr:1 / wave_shl:1) instead of a trip through the LDS crossbar
+__device__ __forceinline__ float lane_prev(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
 // block = 128 threads: wave 0 = alpha (forward), wave 1 = beta (backward)
 template <int R>
 __global__ __launch_bounds__(128) void ctc_lattice_kernel(const int32_t* __restrict__ labels,
@@ -176,56 +186,76 @@ __global__ __launch_bounds__(128) void ctc_lattice_kernel(const int32_t* __restr
     if (dir == 0) {
         // ---------------- alpha
         float cum = 0.f;
-        float e[R];
+        // emissions are fetched CTC_PF steps ahead through a ring of registers: a step is far shorter
+        // than the latency of a load, so a one-step prefetch would leave every step waiting for memory
+        float ring[CTC_PF][R];
+#pragma unroll
+        for (int j = 0; j < CTC_PF; ++j) {
+            const int tj = j < len ? j : len - 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = lane * R + r;
+                ring[j][r] = s < S ? emb[(long)tj * S + s] : CTC_LOGZERO;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int s = lane * R + r;
-            e[r] = s < S ? emb[s] : CTC_LOGZERO;
-            a[r] = (valid[r] && s < 2) ? e[r] : CTC_LOGZERO;
+            a[r] = (valid[r] && s < 2) ? ring[0][r] : CTC_LOGZERO;
         }
-        for (int t = 0; t < len; ++t) {
-            // prefetch the next step's emissions before the dependent math
-            float en[R];
-            const int tn = (t + 1 < len) ? t + 1 : t;
+        for (int tb = 0; tb < len; tb += CTC_PF) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = lane * R + r;
-                en[r] = s < S ? emb[(long)tn * S + s] : CTC_LOGZERO;
-            }
-            if (t > 0) {
-                // neighbours: state s-1 and s-2; across the lane boundary they live in lane-1
-                const float p1 = __shfl_up(a[R - 1], 1, 64);
-                const float p2 = __shfl_up(R >= 2 ? a[R - 2] : a[R - 1], 1, 64);
-                const float q2 = (R == 1) ? __shfl_up(a[0], 2, 64) : 0.f;
-                float na[R];
+            for (int j = 0; j < CTC_PF; ++j) {
+                const int t = tb + j;
+                if (t >= len) break;
+                float e[R];
+                const int tn = (t + CTC_PF < len) ? t + CTC_PF : len - 1;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    float x1, x2;
-                    if (r >= 1) x1 = a[r - 1];
-                    else x1 = lane > 0 ? p1 : CTC_LOGZERO;
-                    if (r >= 2) x2 = a[r - 2];
-                    else if (R == 1) x2 = lane > 1 ? q2 : CTC_LOGZERO;
-                    else if (r == 1) x2 = lane > 0 ? p1 : CTC_LOGZERO;
-                    else x2 = lane > 0 ? p2 : CTC_LOGZERO;
-                    if (!skip_in[r]) x2 = CTC_LOGZERO;
-                    float v = lse3(a[r], x1, x2) + e[r];
-                    na[r] = valid[r] ? v : CTC_LOGZERO;
+                    const int s = lane * R + r;
+                    e[r] = ring[j][r];
+                    ring[j][r] = s < S ? emb[(long)tn * S + s] : CTC_LOGZERO;
                 }
+                if (t > 0) {
+                    // neighbours: state s-1 and s-2; across the lane boundary they live in lane-1
+                    const float p1 = lane_prev(a[R - 1], CTC_LOGZERO);
+                    const float p2 = lane_prev(R >= 2 ? a[R - 2] : a[R - 1], CTC_LOGZERO);
+                    const float q2 = (R == 1) ? lane_prev(p1, CTC_LOGZERO) : 0.f;
+                    float na[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = na[r];
-            }
-            // renormalise by the maximum over states
-            float mx = a[0];
+                    for (int r = 0; r < R; ++r) {
+                        float x1, x2;
+                        if (r >= 1) x1 = a[r - 1];
+                        else x1 = p1;
+                        if (r >= 2) x2 = a[r - 2];
+                        else if (R == 1) x2 = q2;
+                        else if (r == 1) x2 = p1;
+                        else x2 = p2;
+                        if (!skip_in[r]) x2 = CTC_LOGZERO;
+                        float v = lse3(a[r], x1, x2) + e[r];
+                        na[r] = valid[r] ? v : CTC_LOGZERO;
+                    }
 #pragma unroll
-            for (int r = 1; r < R; ++r) mx = fmaxf(mx, a[r]);
-            mx = wave_max(mx);
-            cum += mx;
+                    for (int r = 0; r < R; ++r) a[r] = na[r];
+                }
+                // renormalise by the maximum over states.  The values are logarithms, so this only
+                // keeps them small for the sake of fp32 resolution (the gradient kernel subtracts
+                // alpha + beta from the log-likelihood): every fourth step is enough, and the
+                // cross-lane maximum is the longest dependency chain of a step.
+                float mx = 0.f;
+                if ((t & 3) == 0 || t == len - 1) {
+                    mx = a[0];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                a[r] = valid[r] ? fmaxf(a[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
-                const int s = lane * R + r;
-                if (s < S) alpha[((long)b * T_ + t) * S + s] = a[r];
-                e[r] = en[r];
+                    for (int r = 1; r < R; ++r) mx = fmaxf(mx, a[r]);
+                    mx = wave_max(mx);
+                }
+                cum += mx;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    a[r] = valid[r] ? fmaxf(a[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
+                    const int s = lane * R + r;
+                    if (s < S) alpha[((long)b * T_ + t) * S + s] = a[r];
+                }
             }
         }
         // log-likelihood from the two final states at t = len-1
@@ -250,50 +280,65 @@ __global__ __launch_bounds__(128) void ctc_lattice_kernel(const int32_t* __restr
             a[r] = fin ? 0.f : CTC_LOGZERO;
             if (s < S) beta[((long)b * T_ + (len - 1)) * S + s] = a[r];
         }
-        float e[R];
+        // step t (going down from len-2) consumes the emissions of t+1; ring slot j of a trip holds
+        // the emissions of time t+1 for t = top - j
+        float ring[CTC_PF][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int s = lane * R + r;
-            e[r] = s < S ? emb[(long)(len - 1) * S + s] : CTC_LOGZERO;
+        for (int j = 0; j < CTC_PF; ++j) {
+            const int tj = (len - 1 - j) >= 0 ? len - 1 - j : 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int s = lane * R + r;
+                ring[j][r] = s < S ? emb[(long)tj * S + s] : CTC_LOGZERO;
+            }
         }
-        for (int t = len - 2; t >= 0; --t) {
-            float en[R];
+        for (int top = len - 2; top >= 0; top -= CTC_PF) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = lane * R + r;
-                en[r] = s < S ? emb[(long)t * S + s] : CTC_LOGZERO;
-            }
-            // w[s] = beta[t+1][s] + em[t+1][s]
-            float w[R];
+            for (int j = 0; j < CTC_PF; ++j) {
+                const int t = top - j;
+                if (t < 0) break;
+                float e[R];
+                const int tn = (t + 1 - CTC_PF) >= 0 ? t + 1 - CTC_PF : 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) w[r] = valid[r] ? a[r] + e[r] : CTC_LOGZERO;
-            const float n1 = __shfl_down(w[0], 1, 64);
-            const float n2 = __shfl_down(R >= 2 ? w[1] : w[0], 1, 64);
-            const float m2 = (R == 1) ? __shfl_down(w[0], 2, 64) : 0.f;
-            float nb[R];
+                for (int r = 0; r < R; ++r) {
+                    const int s = lane * R + r;
+                    e[r] = ring[j][r];
+                    ring[j][r] = s < S ? emb[(long)tn * S + s] : CTC_LOGZERO;
+                }
+                // w[s] = beta[t+1][s] + em[t+1][s]
+                float w[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float x1, x2;
-                if (r + 1 < R) x1 = w[r + 1];
-                else x1 = lane < 63 ? n1 : CTC_LOGZERO;
-                if (r + 2 < R) x2 = w[r + 2];
-                else if (R == 1) x2 = lane < 62 ? m2 : CTC_LOGZERO;
-                else if (r + 2 == R) x2 = lane < 63 ? n1 : CTC_LOGZERO;
-                else x2 = lane < 63 ? n2 : CTC_LOGZERO;
-                if (!skip_out[r]) x2 = CTC_LOGZERO;
-                float v = lse3(w[r], x1, x2);
-                nb[r] = valid[r] ? v : CTC_LOGZERO;
-            }
-            float mx = nb[0];
+                for (int r = 0; r < R; ++r) w[r] = valid[r] ? a[r] + e[r] : CTC_LOGZERO;
+                const float n1 = lane_next(w[0], CTC_LOGZERO);
+                const float n2 = lane_next(R >= 2 ? w[1] : w[0], CTC_LOGZERO);
+                const float m2 = (R == 1) ? lane_next(n1, CTC_LOGZERO) : 0.f;
+                float nb[R];
 #pragma unroll
-            for (int r = 1; r < R; ++r) mx = fmaxf(mx, nb[r]);
-            mx = wave_max(mx);
+                for (int r = 0; r < R; ++r) {
+                    float x1, x2;
+                    if (r + 1 < R) x1 = w[r + 1];
+                    else x1 = n1;
+                    if (r + 2 < R) x2 = w[r + 2];
+                    else if (R == 1) x2 = m2;
+                    else if (r + 2 == R) x2 = n1;
+                    else x2 = n2;
+                    if (!skip_out[r]) x2 = CTC_LOGZERO;
+                    float v = lse3(w[r], x1, x2);
+                    nb[r] = valid[r] ? v : CTC_LOGZERO;
+                }
+                float mx = 0.f;
+                if ((t & 3) == 0) {
+                    mx = nb[0];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                a[r] = valid[r] ? fmaxf(nb[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
-                const int s = lane * R + r;
-                if (s < S) beta[((long)b * T_ + t) * S + s] = a[r];
-                e[r] = en[r];
+                    for (int r = 1; r < R; ++r) mx = fmaxf(mx, nb[r]);
+                    mx = wave_max(mx);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    a[r] = valid[r] ? fmaxf(nb[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
+                    const int s = lane * R + r;
+                    if (s < S) beta[((long)b * T_ + t) * S + s] = a[r];
+                }
             }
         }
     }
