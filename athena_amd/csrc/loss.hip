@@ -3,44 +3,56 @@
 // streamed with 16-byte loads and reduced with wavefront shuffles.
 //
 // CTC is three kernels:
-//   ctc_prep   : one workgroup per (b,t) row: logsumexp over V and the gather of the 2U+1
-//                lattice emissions  em[b,t,s] = logit[b,t,ext_b[s]] - lse[b,t]
-//   ctc_lattice: one workgroup of two wavefronts per sample: wavefront 0 runs the alpha
-//                recursion forward in time, wavefront 1 the beta recursion backward; each lane
-//                owns R consecutive lattice states in registers, neighbours come from lane
-//                shuffles, every step is renormalised by the wavefront maximum (the normalisers
-//                are summed separately) so fp32 keeps full precision over hundreds of steps
+//   ctc_fwd    : the lattice workgroups (one per sample: alpha and beta recursions in two
+//                wavefronts, states in registers) and the row workgroups (logsumexp of one logits
+//                row each) in one launch, so the serial recursion overlaps the streaming pass
+//   ctc_finish : per-sample loss from the lattice path sum and the row normalisers
 //   ctc_grad   : one workgroup per row: posterior = normalise(alpha+beta) scattered by class
 //                into an LDS accumulator, then grad = scale * (softmax - occupancy) streamed out
 #include "common.h"
 
 #define CTC_LOGZERO (-1e30f)
-#define CTC_PF 8                // emission rows fetched ahead of the lattice recursion
 #define CTC_MAX_R 16            // lattice states per lane: supports 2U+1 <= 1024
+#define CTC_LOG2E 1.4426950408889634f
+#define CTC_LN2 0.6931471805599453
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// states per lane the lattice kernel is instantiated for
+static int ctc_launch_r(int S) {
+    const int R = (S + 63) / 64;
+    static const int sizes[] = {1, 2, 3, 4, 5, 7, 10, CTC_MAX_R};
+    for (int v : sizes)
+        if (R <= v) return v;
+    return CTC_MAX_R;
+}
+
 struct CtcWorkspace {
-    float* lse;      // [B*T]
-    float* em;       // [B*T*S]
-    float* alpha;    // [B*T*S] normalised log alpha (emission at t included)
-    float* beta;     // [B*T*S] normalised log beta  (emission at t excluded)
+    float* lse;      // [B*T]     natural-log normaliser of each row (softmax of the gradient)
+    float* nrm;      // [B*T]     lse - logit[blank]: the normaliser relative to the blank logit
+    float* alpha;    // [B*T*Sp]  log2 alpha up to a per-(b,t) constant (emission at t included)
+    float* beta;     // [B*T*Sp]  log2 beta  up to a per-(b,t) constant (emission at t excluded)
+    double* ll;      // [B]       log2 of the path sum over blank-relative emissions (-inf: no path)
+    int Sp;          // row pitch of alpha / beta: 64 * states per lane
 };
 
 static size_t ctc_ws_layout(int B, int T, int U, void* base, CtcWorkspace* ws) {
-    const size_t S = 2 * (size_t)U + 1;
+    const int Sp = 64 * ctc_launch_r(2 * U + 1);
     size_t off = 0;
     char* p = (char*)base;
-    size_t n_lse = align_up(sizeof(float) * (size_t)B * T, 256);
-    size_t n_lat = align_up(sizeof(float) * (size_t)B * T * S, 256);
+    size_t n_row = align_up(sizeof(float) * (size_t)B * T, 256);
+    size_t n_lat = align_up(sizeof(float) * (size_t)B * T * Sp, 256);
     if (ws) ws->lse = (float*)(p + off);
-    off += n_lse;
-    if (ws) ws->em = (float*)(p + off);
-    off += n_lat;
+    off += n_row;
+    if (ws) ws->nrm = (float*)(p + off);
+    off += n_row;
     if (ws) ws->alpha = (float*)(p + off);
     off += n_lat;
     if (ws) ws->beta = (float*)(p + off);
     off += n_lat;
+    if (ws) ws->ll = (double*)(p + off);
+    off += align_up(sizeof(double) * (size_t)B, 256);
+    if (ws) ws->Sp = Sp;
     return off;
 }
 
@@ -100,42 +112,17 @@ __device__ __forceinline__ void row_max_sum<float>(const float* __restrict__ row
     m_out = gm;
 }
 
-// ---------------------------------------------------------------- ctc_prep
-template <typename T>
-__global__ __launch_bounds__(256) void ctc_prep_kernel(const T* __restrict__ logits, int ldl,
-                                                       const int32_t* __restrict__ labels,
-                                                       const int32_t* __restrict__ label_len,
-                                                       const int32_t* __restrict__ logit_len, int T_, int V, int U,
-                                                       int blank, float* __restrict__ lse, float* __restrict__ em) {
-    __shared__ float red[32];
-    const int row = blockIdx.x;
-    const int b = row / T_, t = row - b * T_;
-    if (t >= logit_len[b]) return;
-    const T* lr = logits + (long)row * ldl;
-    float m, s;
-    row_max_sum<T>(lr, V, m, s, red);
-    const float l = m + __logf(s);
-    if (threadIdx.x == 0) lse[row] = l;
-    const int S = 2 * U + 1;
-    const int Sb = 2 * label_len[b] + 1;
-    for (int st = threadIdx.x; st < S; st += blockDim.x) {
-        float e = CTC_LOGZERO;
-        if (st < Sb) {
-            int cls = (st & 1) ? labels[(long)b * U + (st >> 1)] : blank;
-            e = to_f32<T>(lr[cls]) - l;
-        }
-        em[(long)row * S + st] = e;
-    }
+// ---------------------------------------------------------------- lattice arithmetic (log2 domain)
+// log2(2^a + 2^b + 2^c) and log2(2^a + 2^b) on the raw exp2 / log2 units: the largest term
+// contributes exactly 1, so one exponential fewer than terms
+__device__ __forceinline__ float lse3_2(float a, float b, float c) {
+    const float hi = fmaxf(a, fmaxf(b, c));
+    const float lo = fminf(a, fminf(b, c));
+    const float md = __builtin_amdgcn_fmed3f(a, b, c);
+    return hi + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(md - hi) + __builtin_amdgcn_exp2f(lo - hi));
 }
-
-// ---------------------------------------------------------------- ctc_lattice
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-    float m = fmaxf(a, fmaxf(b, c));
-    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
-}
-__device__ __forceinline__ float lse2(float a, float b) {
-    float m = fmaxf(a, b);
-    return m + __logf(__expf(a - m) + __expf(b - m));
+__device__ __forceinline__ float lse2_2(float a, float b) {
+    return fmaxf(a, b) + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 
 // value held by the previous / next lane of the wave (``fill`` where there is none): a single DPP
@@ -146,269 +133,391 @@ __device__ __forceinline__ float lane_prev(float v, float fill) {
 __device__ __forceinline__ float lane_next(float v, float fill) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+}
+// maximum over the wave: four DPP steps inside each row of 16 lanes (quad swaps, half mirror,
+// mirror), then the four row results through scalar registers
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = dpp_max<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = dpp_max<0x141>(v);      // row_half_mirror
+    v = dpp_max<0x140>(v);      // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 
-// block = 128 threads: wave 0 = alpha (forward), wave 1 = beta (backward)
+// R consecutive floats per lane, as the widest stores the count allows
 template <int R>
-__global__ __launch_bounds__(128) void ctc_lattice_kernel(const int32_t* __restrict__ labels,
-                                                          const int32_t* __restrict__ label_len,
-                                                          const int32_t* __restrict__ logit_len, int T_, int U,
-                                                          const float* __restrict__ em, float* __restrict__ alpha,
-                                                          float* __restrict__ beta, float* __restrict__ loss) {
+__device__ __forceinline__ void store_states(float* __restrict__ dst, const float (&a)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 4) *(float4*)(dst + r) = make_float4(a[r], a[r + 1], a[r + 2], a[r + 3]);
+    } else if constexpr (R % 2 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) *(float2*)(dst + r) = make_float2(a[r], a[r + 1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dst[r] = a[r];
+    }
+}
+
+// ---------------------------------------------------------------- ctc forward
+// One launch, two kinds of workgroup.
+//   blockIdx <  B : the lattice of sample b.  Wave 0 runs the alpha recursion forward in time,
+//                   wave 1 the beta recursion backward; each lane owns R consecutive states in
+//                   registers and gets its neighbours by DPP.  Emissions are read straight from
+//                   the logits relative to the blank logit of the row,
+//                       e[t][s] = (logit[t][ext[s]] - logit[t][blank]) * log2(e),
+//                   so the lattice does not wait for the row normalisers and its values stay
+//                   small wherever blank or the label dominates; the per-row constant
+//                   lse - logit[blank] is summed back by ctc_finish.  Every fourth step the state
+//                   vector is shifted by its maximum (kept in a double) to hold fp32 resolution.
+//   blockIdx >= B : one logits row each: logsumexp over V.
+// The lattice workgroups are dispatched first and run for the length of the recursion while the
+// rest of the chip streams the rows.
+template <typename T, int R>
+__global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logits, int ldl,
+                                                      const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ label_len,
+                                                      const int32_t* __restrict__ logit_len, int B, int T_, int V,
+                                                      int U, int blank, float* __restrict__ lse,
+                                                      float* __restrict__ nrm, float* __restrict__ alpha,
+                                                      float* __restrict__ beta, double* __restrict__ ll) {
+    __shared__ float red[32];
+    if ((int)blockIdx.x >= B) {
+        const int row = blockIdx.x - B;
+        const int b = row / T_, t = row - b * T_;
+        if (t >= logit_len[b]) return;
+        const T* lr = logits + (long)row * ldl;
+        float m, s;
+        row_max_sum<T>(lr, V, m, s, red);
+        if (threadIdx.x == 0) {
+            const float ls = __logf(s);
+            lse[row] = m + ls;
+            nrm[row] = (m - to_f32<T>(lr[blank])) + ls;
+        }
+        return;
+    }
+    if (threadIdx.x >= 128) return;
+    // the recursion is one long dependency chain: let it issue ahead of the row workgroups that
+    // share its SIMD
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int Sp = 64 * R;
+    constexpr bool kParity = (R % 2) == 0;      // state parity is then a property of r alone
+    // emission rows fetched ahead of the recursion (a step is some 300 cycles, a load under the
+    // row workgroups' traffic a few microseconds).  Measured on gfx950: 12 and 16 steps ahead run
+    // the recursion at its arithmetic pace; 20 and more are twice as slow.
+    constexpr int CTC_PF = R <= 2 ? 16 : 8;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = threadIdx.x >> 6;
-    const int S = 2 * U + 1;
     const int L = label_len[b];
     const int Sb = 2 * L + 1;
     int len = logit_len[b];
     if (len > T_) len = T_;
-    const float* emb = em + (long)b * T_ * S;
     if (len <= 0) {
-        if (dir == 0 && lane == 0) loss[b] = L == 0 ? 0.f : -CTC_LOGZERO;
+        if (dir == 0 && lane == 0) ll[b] = 0.0;
         return;
     }
-    // per-state static data: validity and whether the skip transition (s-2 -> s) is allowed
-    bool valid[R], skip_in[R], skip_out[R];
+    const T* lb = logits + (long)b * T_ * ldl;
+    // per-state static data: class, validity (as an additive penalty) and the skip transitions
+    int cls[R];
+    float pen[R];
+    bool skip_in[R], skip_out[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int s = lane * R + r;
-        valid[r] = s < Sb;
+        int c = blank;
         bool si = false, so = false;
         if ((s & 1) && s < Sb) {
             const int u = s >> 1;
-            if (u >= 1) si = labels[(long)b * U + u] != labels[(long)b * U + u - 1];
-            if (s + 2 < Sb) so = labels[(long)b * U + u + 1] != labels[(long)b * U + u];
+            c = labels[(long)b * U + u];
+            if (u >= 1) si = c != labels[(long)b * U + u - 1];
+            if (s + 2 < Sb) so = labels[(long)b * U + u + 1] != c;
         }
+        cls[r] = (c >= 0 && c < V) ? c : blank;
+        pen[r] = s < Sb ? 0.f : CTC_LOGZERO;
         skip_in[r] = si;
         skip_out[r] = so;
     }
+    // emissions are fetched CTC_PF steps ahead through a ring of registers: a step is far shorter
+    // than the latency of a load, so a one-step prefetch would leave every step waiting for memory
+    T ring[CTC_PF][R];
+    T ringb[CTC_PF];
+    // the blank logit goes through a vector register like the others (a uniform address read as a
+    // scalar would put the whole ring of them into scalar registers, which do not hold that many)
+    int vblank = blank;
+    asm volatile("" : "+v"(vblank));
+    auto fetch = [&](int j, int t) {
+        const T* rowp = lb + (long)t * ldl;
+        ringb[j] = rowp[vblank];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (!(kParity && (r % 2) == 0)) ring[j][r] = rowp[cls[r]];
+    };
+    auto emis = [&](int j, float (&e)[R]) {
+        const float xb = to_f32<T>(ringb[j]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (kParity && (r % 2) == 0) e[r] = pen[r];      // a blank state: logit - logit[blank] = 0
+            else e[r] = fmaf(to_f32<T>(ring[j][r]) - xb, CTC_LOG2E, pen[r]);
+        }
+    };
     float a[R];
     if (dir == 0) {
         // ---------------- alpha
-        float cum = 0.f;
-        // emissions are fetched CTC_PF steps ahead through a ring of registers: a step is far shorter
-        // than the latency of a load, so a one-step prefetch would leave every step waiting for memory
-        float ring[CTC_PF][R];
+        double cum = 0.0;
+        float* ab = alpha + (long)b * T_ * Sp + lane * R;
 #pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) {
-            const int tj = j < len ? j : len - 1;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = lane * R + r;
-                ring[j][r] = s < S ? emb[(long)tj * S + s] : CTC_LOGZERO;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int s = lane * R + r;
-            a[r] = (valid[r] && s < 2) ? ring[0][r] : CTC_LOGZERO;
-        }
+        for (int j = 0; j < CTC_PF; ++j) fetch(j, j < len ? j : len - 1);
         for (int tb = 0; tb < len; tb += CTC_PF) {
 #pragma unroll
             for (int j = 0; j < CTC_PF; ++j) {
                 const int t = tb + j;
-                if (t >= len) break;
+                if (t >= len) continue;
                 float e[R];
-                const int tn = (t + CTC_PF < len) ? t + CTC_PF : len - 1;
+                emis(j, e);
+                fetch(j, (t + CTC_PF < len) ? t + CTC_PF : len - 1);
+                if (j == 0 && t == 0) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int s = lane * R + r;
-                    e[r] = ring[j][r];
-                    ring[j][r] = s < S ? emb[(long)tn * S + s] : CTC_LOGZERO;
-                }
-                if (t > 0) {
+                    for (int r = 0; r < R; ++r) a[r] = (lane * R + r < 2) ? e[r] : CTC_LOGZERO;
+                } else {
                     // neighbours: state s-1 and s-2; across the lane boundary they live in lane-1
                     const float p1 = lane_prev(a[R - 1], CTC_LOGZERO);
-                    const float p2 = lane_prev(R >= 2 ? a[R - 2] : a[R - 1], CTC_LOGZERO);
-                    const float q2 = (R == 1) ? lane_prev(p1, CTC_LOGZERO) : 0.f;
+                    const float p2 = (R >= 2) ? lane_prev(a[R >= 2 ? R - 2 : 0], CTC_LOGZERO)
+                                              : lane_prev(p1, CTC_LOGZERO);
                     float na[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        float x1, x2;
-                        if (r >= 1) x1 = a[r - 1];
-                        else x1 = p1;
-                        if (r >= 2) x2 = a[r - 2];
-                        else if (R == 1) x2 = q2;
-                        else if (r == 1) x2 = p1;
-                        else x2 = p2;
-                        if (!skip_in[r]) x2 = CTC_LOGZERO;
-                        float v = lse3(a[r], x1, x2) + e[r];
-                        na[r] = valid[r] ? v : CTC_LOGZERO;
+                        const float x1 = r >= 1 ? a[r >= 1 ? r - 1 : 0] : p1;
+                        float v;
+                        if (kParity && (r % 2) == 0) {
+                            v = lse2_2(a[r], x1);
+                        } else {
+                            float x2 = r >= 2 ? a[r >= 2 ? r - 2 : 0] : (r == 1 ? p1 : p2);
+                            if (!skip_in[r]) x2 = CTC_LOGZERO;
+                            v = lse3_2(a[r], x1, x2);
+                        }
+                        na[r] = v + e[r];
                     }
 #pragma unroll
                     for (int r = 0; r < R; ++r) a[r] = na[r];
                 }
-                // renormalise by the maximum over states.  The values are logarithms, so this only
-                // keeps them small for the sake of fp32 resolution (the gradient kernel subtracts
-                // alpha + beta from the log-likelihood): every fourth step is enough, and the
-                // cross-lane maximum is the longest dependency chain of a step.
-                float mx = 0.f;
-                if ((t & 3) == 0 || t == len - 1) {
-                    mx = a[0];
+                if ((j & 3) == 0) {
+                    // the values are logarithms: shifting them by the maximum only keeps them small
+                    // for the sake of fp32 resolution, so every fourth step is enough
+                    float mx = a[0];
 #pragma unroll
                     for (int r = 1; r < R; ++r) mx = fmaxf(mx, a[r]);
-                    mx = wave_max(mx);
-                }
-                cum += mx;
+                    mx = wave_max_dpp(mx);
+                    cum += (double)mx;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    a[r] = valid[r] ? fmaxf(a[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
-                    const int s = lane * R + r;
-                    if (s < S) alpha[((long)b * T_ + t) * S + s] = a[r];
+                    for (int r = 0; r < R; ++r) a[r] = fmaxf(a[r] - mx, CTC_LOGZERO);
                 }
+                store_states<R>(ab + (long)t * Sp, a);
             }
         }
-        // log-likelihood from the two final states at t = len-1
+        // path sum from the two final states at t = len-1
         float fin = CTC_LOGZERO;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int s = lane * R + r;
-            if (s == Sb - 1 || (s == Sb - 2 && Sb >= 2)) fin = (fin == CTC_LOGZERO) ? a[r] : lse2(fin, a[r]);
+            if (s == Sb - 1 || (s == Sb - 2 && Sb >= 2)) fin = (fin == CTC_LOGZERO) ? a[r] : lse2_2(fin, a[r]);
         }
-        // combine across lanes (at most two lanes hold a final state)
-        float fm = wave_max(fin);
-        float fs = wave_sum(fin <= CTC_LOGZERO ? 0.f : __expf(fin - fm));
-        // no alignment fits: report the finite log-zero instead of -log(0)
-        if (lane == 0) loss[b] = fs > 0.f ? -(cum + fm + __logf(fs)) : -CTC_LOGZERO;
+        const bool live = fin > 0.5f * CTC_LOGZERO;
+        const float fm = wave_max(live ? fin : CTC_LOGZERO);
+        const float fs = wave_sum(live ? __builtin_amdgcn_exp2f(fin - fm) : 0.f);
+        if (lane == 0) ll[b] = fs > 0.f ? cum + (double)fm + (double)__builtin_amdgcn_logf(fs) : -(double)INFINITY;
     } else {
         // ---------------- beta: beta[len-1][s] = 0 for final states; beta[t][s] = lse over successors
-        // s' in {s, s+1, s+2(skip)} of beta[t+1][s'] + em[t+1][s']
+        // s' in {s, s+1, s+2(skip)} of beta[t+1][s'] + e[t+1][s']
+        float* bb = beta + (long)b * T_ * Sp + lane * R;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int s = lane * R + r;
             const bool fin = (s == Sb - 1) || (s == Sb - 2 && Sb >= 2);
             a[r] = fin ? 0.f : CTC_LOGZERO;
-            if (s < S) beta[((long)b * T_ + (len - 1)) * S + s] = a[r];
         }
+        store_states<R>(bb + (long)(len - 1) * Sp, a);
         // step t (going down from len-2) consumes the emissions of t+1; ring slot j of a trip holds
         // the emissions of time t+1 for t = top - j
-        float ring[CTC_PF][R];
 #pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) {
-            const int tj = (len - 1 - j) >= 0 ? len - 1 - j : 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = lane * R + r;
-                ring[j][r] = s < S ? emb[(long)tj * S + s] : CTC_LOGZERO;
-            }
-        }
+        for (int j = 0; j < CTC_PF; ++j) fetch(j, (len - 1 - j) >= 0 ? len - 1 - j : 0);
         for (int top = len - 2; top >= 0; top -= CTC_PF) {
 #pragma unroll
             for (int j = 0; j < CTC_PF; ++j) {
                 const int t = top - j;
-                if (t < 0) break;
+                if (t < 0) continue;
                 float e[R];
-                const int tn = (t + 1 - CTC_PF) >= 0 ? t + 1 - CTC_PF : 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int s = lane * R + r;
-                    e[r] = ring[j][r];
-                    ring[j][r] = s < S ? emb[(long)tn * S + s] : CTC_LOGZERO;
-                }
-                // w[s] = beta[t+1][s] + em[t+1][s]
+                emis(j, e);
+                fetch(j, (t + 1 - CTC_PF) >= 0 ? t + 1 - CTC_PF : 0);
+                // w[s] = beta[t+1][s] + e[t+1][s]
                 float w[R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) w[r] = valid[r] ? a[r] + e[r] : CTC_LOGZERO;
+                for (int r = 0; r < R; ++r) w[r] = a[r] + e[r];
                 const float n1 = lane_next(w[0], CTC_LOGZERO);
-                const float n2 = lane_next(R >= 2 ? w[1] : w[0], CTC_LOGZERO);
-                const float m2 = (R == 1) ? lane_next(n1, CTC_LOGZERO) : 0.f;
+                const float n2 = (R >= 2) ? lane_next(w[R >= 2 ? 1 : 0], CTC_LOGZERO) : lane_next(n1, CTC_LOGZERO);
                 float nb[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    float x1, x2;
-                    if (r + 1 < R) x1 = w[r + 1];
-                    else x1 = n1;
-                    if (r + 2 < R) x2 = w[r + 2];
-                    else if (R == 1) x2 = m2;
-                    else if (r + 2 == R) x2 = n1;
-                    else x2 = n2;
-                    if (!skip_out[r]) x2 = CTC_LOGZERO;
-                    float v = lse3(w[r], x1, x2);
-                    nb[r] = valid[r] ? v : CTC_LOGZERO;
+                    const float x1 = (r + 1 < R) ? w[r + 1 < R ? r + 1 : 0] : n1;
+                    if (kParity && (r % 2) == 0) {
+                        nb[r] = lse2_2(w[r], x1);
+                    } else {
+                        float x2 = (r + 2 < R) ? w[r + 2 < R ? r + 2 : 0] : (r + 2 == R ? n1 : n2);
+                        if (!skip_out[r]) x2 = CTC_LOGZERO;
+                        nb[r] = lse3_2(w[r], x1, x2);
+                    }
                 }
-                float mx = 0.f;
-                if ((t & 3) == 0) {
-                    mx = nb[0];
+                if ((j & 3) == 0) {
+                    float mx = nb[0];
 #pragma unroll
                     for (int r = 1; r < R; ++r) mx = fmaxf(mx, nb[r]);
-                    mx = wave_max(mx);
+                    mx = wave_max_dpp(mx);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) nb[r] = fmaxf(nb[r] - mx, CTC_LOGZERO);
                 }
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    a[r] = valid[r] ? fmaxf(nb[r] - mx, CTC_LOGZERO) : CTC_LOGZERO;
-                    const int s = lane * R + r;
-                    if (s < S) beta[((long)b * T_ + t) * S + s] = a[r];
-                }
+                for (int r = 0; r < R; ++r) a[r] = nb[r];
+                store_states<R>(bb + (long)t * Sp, a);
             }
         }
     }
 }
 
+// loss[b] = -(ln of the blank-relative path sum - sum over t of (lse - logit[blank])); one wave per sample
+__global__ __launch_bounds__(64) void ctc_finish_kernel(const int32_t* __restrict__ label_len,
+                                                        const int32_t* __restrict__ logit_len, int T_,
+                                                        const float* __restrict__ nrm, const double* __restrict__ ll,
+                                                        float* __restrict__ loss) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int len = logit_len[b];
+    if (len > T_) len = T_;
+    double acc = 0.0;
+    for (int t = lane; t < len; t += 64) acc += (double)nrm[(long)b * T_ + t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        float out;
+        if (len <= 0) out = label_len[b] == 0 ? 0.f : -CTC_LOGZERO;
+        else if (ll[b] == -(double)INFINITY) out = -CTC_LOGZERO;     // no alignment fits: finite log-zero
+        else out = (float)(acc - ll[b] * CTC_LN2);
+        loss[b] = out;
+    }
+}
+
 // ---------------------------------------------------------------- ctc_grad
+// One workgroup per logits row at a time.  The row is fetched into registers first; while it is in
+// flight every wave works out the normaliser of the state posterior alpha+beta for itself (no
+// workgroup barrier), the states are scattered by class into an LDS accumulator, and then
+// grad = scale * (softmax - occupancy) is streamed out, each thread clearing the accumulator
+// entries it consumed.
 #define CTC_OCC_CHUNK 8192
+#define CTC_GRAD_VEC 8          // 4-wide column groups per thread and chunk: 256 * 8 * 4 = CTC_OCC_CHUNK
+template <typename TL>
+struct CtcRowVec;
+template <>
+struct CtcRowVec<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *(const float4*)p; }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <>
+struct CtcRowVec<bf16_t> {
+    uint2 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const uint2*)p; }
+    __device__ __forceinline__ float get(int i) const {
+        const uint32_t w = i < 2 ? v.x : v.y;
+        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+};
+template <typename TG>
+__device__ __forceinline__ void ctc_store4(TG* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void ctc_store4<float>(float* p, float a, float b, float c, float d) {
+    *(float4*)p = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void ctc_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    union { bf16_t h[4]; uint2 u; } pk;
+    pk.h[0] = (bf16_t)a; pk.h[1] = (bf16_t)b; pk.h[2] = (bf16_t)c; pk.h[3] = (bf16_t)d;
+    *(uint2*)p = pk.u;
+}
+
 template <typename TL, typename TG>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const TL* __restrict__ logits, int ldl,
                                                        const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
                                                        const int32_t* __restrict__ logit_len, int T_, int V, int U,
-                                                       int blank, const float* __restrict__ lse,
+                                                       int blank, int Sp, const float* __restrict__ lse,
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ grad_scale, float host_scale,
-                                                       TG* __restrict__ grad, int rows_total) {
-    __shared__ float occ[CTC_OCC_CHUNK];
-    __shared__ float red[32];
-    const int S = 2 * U + 1;
-    for (int c = threadIdx.x; c < CTC_OCC_CHUNK; c += blockDim.x) occ[c] = 0.f;
+                                                       TG* __restrict__ grad, int rows_total, int chunk) {
+    extern __shared__ float occ[];       // [chunk]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < chunk; c += blockDim.x) occ[c] = 0.f;
     __syncthreads();
     const float scale = host_scale * (grad_scale ? grad_scale[0] : 1.f);
+    // columns [0, ldl) are written: logits columns get the gradient, the padding zeros.  ldl % 4 == 0.
     for (int row = blockIdx.x; row < rows_total; row += gridDim.x) {
         const int b = row / T_, t = row - b * T_;
         TG* gr = grad + (long)row * ldl;
         if (t >= logit_len[b]) {
-            for (int c = threadIdx.x; c < ldl; c += blockDim.x) gr[c] = from_f32<TG>(0.f);
+            for (int c = threadIdx.x * 4; c < ldl; c += blockDim.x * 4) ctc_store4<TG>(gr + c, 0.f, 0.f, 0.f, 0.f);
             continue;
         }
         const int Sb = 2 * label_len[b] + 1;
-        const float* ar = alpha + (long)row * S;
-        const float* br = beta + (long)row * S;
-        // posterior over lattice states, normalised per time step
-        float mx = -INFINITY;
-        for (int s = threadIdx.x; s < Sb; s += blockDim.x) mx = fmaxf(mx, ar[s] + br[s]);
-        mx = block_max(mx, red);
-        float sm = 0.f;
-        for (int s = threadIdx.x; s < Sb; s += blockDim.x) sm += __expf(ar[s] + br[s] - mx);
-        sm = block_sum(sm, red);
-        const float inv = 1.f / sm;
+        const float* ar = alpha + (long)row * Sp;
+        const float* br = beta + (long)row * Sp;
         const TL* lr = logits + (long)row * ldl;
         const float l = lse[row];
-        for (int v0 = 0; v0 < V; v0 += CTC_OCC_CHUNK) {
-            const int v1 = min(V, v0 + CTC_OCC_CHUNK);
-            for (int s = threadIdx.x; s < Sb; s += blockDim.x) {
+        for (int v0 = 0; v0 < ldl; v0 += chunk) {
+            // the row (this chunk of it) into registers
+            CtcRowVec<TL> x[CTC_GRAD_VEC];
+#pragma unroll
+            for (int i = 0; i < CTC_GRAD_VEC; ++i) {
+                const int c = v0 + (i * 256 + threadIdx.x) * 4;
+                if (i * 1024 < chunk && c < ldl) x[i].load(lr + c);
+            }
+            // posterior over the lattice states of this row: every wave normalises for itself
+            float mx = -INFINITY;
+            for (int s = lane; s < Sb; s += 64) mx = fmaxf(mx, ar[s] + br[s]);
+            mx = wave_max(mx);
+            float sm = 0.f;
+            for (int s = lane; s < Sb; s += 64) sm += __builtin_amdgcn_exp2f(ar[s] + br[s] - mx);
+            sm = wave_sum(sm);
+            const float inv = 1.f / sm;
+            for (int s = threadIdx.x; s < Sb; s += 256) {
                 const int cls = (s & 1) ? labels[(long)b * U + (s >> 1)] : blank;
-                if (cls >= v0 && cls < v1) atomicAdd(&occ[cls - v0], __expf(ar[s] + br[s] - mx) * inv);
+                if (cls >= v0 && cls < v0 + chunk && cls < V)
+                    atomicAdd(&occ[cls - v0], __builtin_amdgcn_exp2f(ar[s] + br[s] - mx) * inv);
             }
             __syncthreads();
-            for (int c = v0 + threadIdx.x; c < v1; c += blockDim.x) {
-                const float p = __expf(to_f32<TL>(lr[c]) - l);
-                gr[c] = from_f32<TG>(scale * (p - occ[c - v0]));
-            }
-            __syncthreads();
-            for (int s = threadIdx.x; s < Sb; s += blockDim.x) {
-                const int cls = (s & 1) ? labels[(long)b * U + (s >> 1)] : blank;
-                if (cls >= v0 && cls < v1) occ[cls - v0] = 0.f;
+#pragma unroll
+            for (int i = 0; i < CTC_GRAD_VEC; ++i) {
+                const int cl = (i * 256 + threadIdx.x) * 4;     // column within the chunk
+                const int c = v0 + cl;
+                if (i * 1024 < chunk && c < ldl) {
+                    const float4 o = *(const float4*)(occ + cl);
+                    if (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) *(float4*)(occ + cl) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float g[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float ok = k == 0 ? o.x : k == 1 ? o.y : k == 2 ? o.z : o.w;
+                        g[k] = (c + k < V) ? scale * (__expf(x[i].get(k) - l) - ok) : 0.f;
+                    }
+                    ctc_store4<TG>(gr + c, g[0], g[1], g[2], g[3]);
+                }
             }
             __syncthreads();
         }
-        for (int c = V + threadIdx.x; c < ldl; c += blockDim.x) gr[c] = from_f32<TG>(0.f);
     }
-}
-
-template <int R>
-static void launch_lattice(int B, hipStream_t s, const int32_t* labels, const int32_t* label_len,
-                           const int32_t* logit_len, int T, int U, const CtcWorkspace& ws, float* loss) {
-    hipLaunchKernelGGL(ctc_lattice_kernel<R>, dim3(B), dim3(128), 0, s, labels, label_len, logit_len, T, U, ws.em,
-                       ws.alpha, ws.beta, loss);
 }
 
 static int ctc_check(const char* name, const void* logits, int dtype, int ldl, int B, int T, int V, int U, int blank,
@@ -423,6 +532,32 @@ static int ctc_check(const char* name, const void* logits, int dtype, int ldl, i
     return ATHENA_OK;
 }
 
+template <typename T, int R>
+static void launch_ctc_fwd(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
+                           const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
+                           hipStream_t s) {
+    hipLaunchKernelGGL((ctc_fwd_kernel<T, R>), dim3(B + B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len,
+                       logit_len, B, Tn, V, U, blank, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll);
+}
+
+template <typename T>
+static void dispatch_ctc_fwd(int R, const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
+                             const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
+                             hipStream_t s) {
+#define CTC_FWD(N) launch_ctc_fwd<T, N>(logits, ldl, labels, label_len, logit_len, B, Tn, V, U, blank, ws, s)
+    switch (R) {
+        case 1: CTC_FWD(1); break;
+        case 2: CTC_FWD(2); break;
+        case 3: CTC_FWD(3); break;
+        case 4: CTC_FWD(4); break;
+        case 5: CTC_FWD(5); break;
+        case 7: CTC_FWD(7); break;
+        case 10: CTC_FWD(10); break;
+        default: CTC_FWD(CTC_MAX_R); break;
+    }
+#undef CTC_FWD
+}
+
 extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
                                    const int32_t* label_len, const int32_t* logit_len, int B, int T, int V, int U,
                                    int blank, float* loss, void* workspace, size_t workspace_bytes,
@@ -433,20 +568,12 @@ extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl
     CtcWorkspace ws;
     ctc_ws_layout(B, T, U, workspace, &ws);
     hipStream_t s = (hipStream_t)stream;
+    const int R = ctc_launch_r(2 * U + 1);
     if (logits_dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(ctc_prep_kernel<bf16_t>, dim3(B * T), dim3(256), 0, s, (const bf16_t*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.lse, ws.em);
+        dispatch_ctc_fwd<bf16_t>(R, (const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, s);
     else
-        hipLaunchKernelGGL(ctc_prep_kernel<float>, dim3(B * T), dim3(256), 0, s, (const float*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.lse, ws.em);
-    const int S = 2 * U + 1;
-    const int R = (S + 63) / 64;
-    if (R <= 1) launch_lattice<1>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 2) launch_lattice<2>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 3) launch_lattice<3>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 4) launch_lattice<4>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 5) launch_lattice<5>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 7) launch_lattice<7>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else if (R <= 10) launch_lattice<10>(B, s, labels, label_len, logit_len, T, U, ws, loss);
-    else launch_lattice<CTC_MAX_R>(B, s, labels, label_len, logit_len, T, U, ws, loss);
+        dispatch_ctc_fwd<float>(R, (const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, s);
+    hipLaunchKernelGGL(ctc_finish_kernel, dim3(B), dim3(64), 0, s, label_len, logit_len, T, ws.nrm, ws.ll, loss);
     ATHENA_CHECK_LAUNCH("athena_ctc_loss_fwd");
     return ATHENA_OK;
 }
@@ -459,15 +586,19 @@ extern "C" int athena_ctc_loss_bwd(const void* logits, int logits_dtype, int ldl
     if (rc) return rc;
     ATHENA_REQUIRE(labels && label_len && logit_len && grad, ATHENA_E_SHAPE, "athena_ctc_loss_bwd: null operand");
     ATHENA_REQUIRE(grad_dtype == ATHENA_F32 || grad_dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "athena_ctc_loss_bwd: grad dtype");
+    ATHENA_REQUIRE(athena_aligned16(grad), ATHENA_E_ALIGN, "athena_ctc_loss_bwd: grad must be 16-byte aligned");
     CtcWorkspace ws;
     ctc_ws_layout(B, T, U, workspace, &ws);
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * T;
     const int grid = rows < 2048 ? rows : 2048;
+    // the occupancy accumulator covers the padded row in one piece when it fits
+    int chunk = (ldl + 1023) / 1024 * 1024;
+    if (chunk > CTC_OCC_CHUNK) chunk = CTC_OCC_CHUNK;
 #define CTC_GRAD(TL, TG)                                                                                          \
-    hipLaunchKernelGGL((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), 0, s, (const TL*)logits, ldl, labels,    \
-                       label_len, logit_len, T, V, U, blank, ws.lse, ws.alpha, ws.beta, grad_scale, host_scale,   \
-                       (TG*)grad, rows)
+    hipLaunchKernelGGL((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), chunk * sizeof(float), s,                \
+                       (const TL*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse,       \
+                       ws.alpha, ws.beta, grad_scale, host_scale, (TG*)grad, rows, chunk)
     if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CTC_GRAD(float, float);
     else if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_BF16) CTC_GRAD(float, bf16_t);
     else if (logits_dtype == ATHENA_BF16 && grad_dtype == ATHENA_BF16) CTC_GRAD(bf16_t, bf16_t);
