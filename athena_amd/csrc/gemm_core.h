@@ -339,7 +339,7 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
     // for its turn to be written to the other LDS stage and the loads of tile t+2 are in flight
     // into the other set, so a global load has two tile-times to arrive
     uint4 ra0[NCH], rb0[NCH], ra1[NCH], rb1[NCH];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint32_t km0 = 0, km1 = 0;
     // column sums of B (bias gradient of a weight-gradient GEMM): in the first row of workgroups
     // the waves with wm == 0 multiply their B fragments with an all-ones A fragment as well, which
     // leaves sum_k B(k, n) in every column of one extra accumulator per 16 columns
@@ -356,7 +356,14 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
     int ld_t = t_begin;
     int ld_seg = AMap::kSegmented ? t_begin / tiles_per_seg : 0;
     int ld_k0 = (t_begin - ld_seg * tiles_per_seg) * GM_BK;
-    auto load_tile = [&](uint4 (&ra)[NCH], uint4 (&rb)[NCH]) {
+    // A tile is fetched into a register set together with a mask of the pieces that lie inside the
+    // matrices (bit i: A piece i, bit 8 + i: B piece i); pieces outside are read from a valid
+    // address and zeroed when the set is written to LDS.  The loaded registers are not touched
+    // between the load and that write, on any path, so the loads of the following tiles stay in
+    // flight behind them (a use right after the load, or on one arm of a branch only, would make
+    // the wait for an older tile cover the younger ones as well).
+    constexpr uint32_t KM_FULL = ((1u << NCH) - 1u) * 0x101u;
+    auto load_tile = [&](uint4 (&ra)[NCH], uint4 (&rb)[NCH], uint32_t& km) {
         const bool live = ld_t < t_end;
         const int seg = live ? ld_seg : 0;
         const int k0 = ld_k0;
@@ -364,23 +371,20 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
         ++ld_t;
         ld_k0 += GM_BK;
         if (AMap::kSegmented && ld_k0 >= p.kseg) { ld_k0 = 0; ++ld_seg; }
-        // Zero-filling is done by AND-ing the loaded words with a mask after an always-valid load
-        // (a select between a load and zero would be turned into a load through a selected pointer
-        // to a zero kept in scratch memory).
+        uint32_t m = 0;
         if (live && k0 + GM_BK <= p.kseg) {
             // whole tile inside the contraction range (the common case)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
                 long o = p.amap.off(arow[i], seg_base + seg);
-                uint32_t keep = 0xffffffffu;
+                bool ok = true;
                 if (AMap::kCanMiss) {
-                    keep = o >= 0 ? 0xffffffffu : 0u;
-                    o = o >= 0 ? o : 0;
+                    ok = o >= 0;
+                    o = ok ? o : 0;
                 }
-                uint4 v = *(const uint4*)(A + o + (TA ? acol[i] : k0 + acol[i]));
-                if (AMap::kCanMiss) { v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep; }
-                ra[i] = v;
+                ra[i] = *(const uint4*)(A + o + (TA ? acol[i] : k0 + acol[i]));
                 rb[i] = *(const uint4*)(pb[i] + bseg + (TB ? (long)k0 : (long)k0 * p.ldb));
+                m |= ((ok ? 1u : 0u) << i) | (1u << (8 + i));
             }
         } else {
             // the last, partial tile of a segment, or a tile index past the end (all zeros)
@@ -392,31 +396,44 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
                 const long o = p.amap.off(arow[i], seg_base + seg);
                 const bool oka = live && ka < p.kseg && o >= 0;
                 const bool okb = live && kb < p.kseg;
-                const uint32_t keepa = oka ? 0xffffffffu : 0u, keepb = okb ? 0xffffffffu : 0u;
                 const long offa = oka ? o + (TA ? acol[i] : ka) : 0;
                 const bf16_t* ptrb = okb ? pb[i] + bseg + (TB ? (long)k0 : (long)k0 * p.ldb) : B;
-                uint4 va = *(const uint4*)(A + offa), vb = *(const uint4*)ptrb;
-                va.x &= keepa; va.y &= keepa; va.z &= keepa; va.w &= keepa;
-                vb.x &= keepb; vb.y &= keepb; vb.z &= keepb; vb.w &= keepb;
-                ra[i] = va;
-                rb[i] = vb;
+                ra[i] = *(const uint4*)(A + offa);
+                rb[i] = *(const uint4*)ptrb;
+                m |= ((oka ? 1u : 0u) << i) | ((okb ? 1u : 0u) << (8 + i));
             }
         }
+        km = m;
         if (TA) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) p.amap.step(arow[i], GM_BK);
         }
     };
-    auto store_tile = [&](int buf, const uint4 (&ra)[NCH], const uint4 (&rb)[NCH]) {
+    auto store_tile = [&](int buf, const uint4 (&ra)[NCH], const uint4 (&rb)[NCH], const uint32_t km) {
         bf16_t* sA = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* sB = sA + A_ELEMS;
+        if (__builtin_amdgcn_ballot_w64(km != KM_FULL) == 0) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            if (!TA) *(uint4*)(sA + row_img_off(c >> 3, c & 7)) = ra[i];
-            else *(uint4*)(sA + tr_img_off<NC>(c / NC, c % NC)) = ra[i];
-            if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = rb[i];
-            else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = rb[i];
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i;
+                if (!TA) *(uint4*)(sA + row_img_off(c >> 3, c & 7)) = ra[i];
+                else *(uint4*)(sA + tr_img_off<NC>(c / NC, c % NC)) = ra[i];
+                if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = rb[i];
+                else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = tid + 256 * i;
+                const uint32_t ma = ((km >> i) & 1u) ? 0xffffffffu : 0u;
+                const uint32_t mb = ((km >> (8 + i)) & 1u) ? 0xffffffffu : 0u;
+                const uint4 va = make_uint4(ra[i].x & ma, ra[i].y & ma, ra[i].z & ma, ra[i].w & ma);
+                const uint4 vb = make_uint4(rb[i].x & mb, rb[i].y & mb, rb[i].z & mb, rb[i].w & mb);
+                if (!TA) *(uint4*)(sA + row_img_off(c >> 3, c & 7)) = va;
+                else *(uint4*)(sA + tr_img_off<NC>(c / NC, c % NC)) = va;
+                if (TB) *(uint4*)(sB + row_img_off(c >> 3, c & 7)) = vb;
+                else *(uint4*)(sB + tr_img_off<NC>(c / NC, c % NC)) = vb;
+            }
         }
     };
     auto multiply_tile = [&](int buf) {
@@ -457,36 +474,36 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
         if constexpr (PF2) {
             // tiles are taken in pairs; a tile index past t_end loads as zeros and multiplies to
             // nothing, which keeps the loop body free of exits (one accumulator set, fixed register roles)
-            load_tile(ra0, rb0);
-            load_tile(ra1, rb1);
-            store_tile(0, ra0, rb0);
+            load_tile(ra0, rb0, km0);
+            load_tile(ra1, rb1, km1);
+            store_tile(0, ra0, rb0, km0);
             __syncthreads();
 #pragma nounroll
             for (int t = t_begin; t < t_end; t += 2) {
                 // LDS stage 0 holds tile t, set 1 holds tile t+1
-                load_tile(ra0, rb0);
+                load_tile(ra0, rb0, km0);
                 multiply_tile(0);
-                store_tile(1, ra1, rb1);
+                store_tile(1, ra1, rb1, km1);
                 __syncthreads();
                 // LDS stage 1 holds tile t+1, set 0 holds tile t+2
-                load_tile(ra1, rb1);
+                load_tile(ra1, rb1, km1);
                 multiply_tile(1);
-                store_tile(0, ra0, rb0);
+                store_tile(0, ra0, rb0, km0);
                 __syncthreads();
             }
         } else {
-            load_tile(ra0, rb0);
-            store_tile(0, ra0, rb0);
+            load_tile(ra0, rb0, km0);
+            store_tile(0, ra0, rb0, km0);
             __syncthreads();
 #pragma nounroll
             for (int t = t_begin; t < t_end; t += 2) {
-                load_tile(ra0, rb0);
+                load_tile(ra0, rb0, km0);
                 multiply_tile(0);
-                store_tile(1, ra0, rb0);
+                store_tile(1, ra0, rb0, km0);
                 __syncthreads();
-                load_tile(ra0, rb0);
+                load_tile(ra0, rb0, km0);
                 multiply_tile(1);
-                store_tile(0, ra0, rb0);
+                store_tile(0, ra0, rb0, km0);
                 __syncthreads();
             }
         }
