@@ -42,6 +42,17 @@ class MultiHeadAttention(nn.Module):
         self.wk = Dense(store, name + ".wk", d_model, d_model, init)
         self.wv = Dense(store, name + ".wv", d_model, d_model, init)
         self.dense = Dense(store, name + ".dense", d_model, d_model, init)
+        # one fused bf16 copy [d, 3d] of the three projection kernels: the input gradients of the
+        # projections that share an input are then a single product
+        if d_model % 8 == 0:
+            store.group_shadows([name + ".wq.kernel", name + ".wk.kernel", name + ".wv.kernel"])
+        self._qkv_shadow = None
+
+    def qkv_shadow(self):
+        """Fused row-major bf16 copy [d, 3d] of (wq | wk | wv), or None in fp32 mode."""
+        if self._qkv_shadow is None and self.store.shadow is not None and self.d_model % 8 == 0:
+            self._qkv_shadow = self.store.group_shadow_views(self.wq.vname + ".kernel")[0]
+        return self._qkv_shadow
 
     def forward(self, v, k, q, mask):
         """Returns (output, None): the [B,h,Tq,Tk] attention weights are never materialised."""

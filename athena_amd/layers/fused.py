@@ -132,18 +132,42 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
     safe = dout.data_ptr() not in (dq_in.data_ptr(), dkv_in.data_ptr())
     lin_bwd_w(ctx, dout, Mq, attn.dense, d, d, defer=safe)
     dctx = lin_bwd_x(dout, Mq, attn.dense, d)
-    dq = torch.empty_like(q)
-    dk_ = torch.empty_like(k)
-    dv = torch.empty_like(v)
     delta = torch.empty_like(lse)
+    fused = attn.qkv_shadow() if q.dtype == torch.bfloat16 else None
+    same_in = q_in.data_ptr() == kv_in.data_ptr() and Mq == Mk and dq_in.data_ptr() == dkv_in.data_ptr()
+    if fused is not None and same_in:
+        # self-attention: dq | dk | dv side by side, so the gradient of the shared input is one
+        # product with the fused [d, 3d] copy of the three kernels
+        dqkv = torch.empty((Mq, 3 * d), dtype=q.dtype, device=q.device)
+        dq, dk_, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        ld = 3 * d
+    elif fused is not None:
+        # cross-attention: dk | dv side by side for the gradient of the memory
+        dq = torch.empty_like(q)
+        dkv = torch.empty((Mk, 2 * d), dtype=k.dtype, device=k.device)
+        dk_, dv = dkv[:, :d], dkv[:, d:]
+        ld = 2 * d
+    else:
+        dq = torch.empty_like(q)
+        dk_ = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        ld = d
+    lddq = ld if (fused is not None and same_in) else d
     ops.mha_bwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, dctx, d, lse,
-                delta, dq, dk_, dv, d, d, d)
-    lin_bwd_w(q_in, dq, Mq, attn.wq, d, d)
-    lin_bwd_w(kv_in, dk_, Mk, attn.wk, d, d)
-    lin_bwd_w(kv_in, dv, Mk, attn.wv, d, d)
-    lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
-    lin_bwd_x(dk_, Mk, attn.wk, d, out=dkv_in, accumulate=acc_kv)
-    lin_bwd_x(dv, Mk, attn.wv, d, out=dkv_in, accumulate=True)
+                delta, dq, dk_, dv, lddq, ld, ld)
+    lin_bwd_w(q_in, dq, Mq, attn.wq, d, lddq)
+    lin_bwd_w(kv_in, dk_, Mk, attn.wk, d, ld)
+    lin_bwd_w(kv_in, dv, Mk, attn.wv, d, ld)
+    if fused is not None and same_in:
+        ops.gemm(dqkv, fused, dq_in, Mq, d, 3 * d, trans_b=True, lda=3 * d, ldb=3 * d, ldc=d, accumulate=acc_q)
+    elif fused is not None:
+        lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
+        ops.gemm(dkv, fused[:, d:], dkv_in, Mk, d, 2 * d, trans_b=True, lda=2 * d, ldb=3 * d, ldc=d,
+                 accumulate=acc_kv)
+    else:
+        lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
+        lin_bwd_x(dk_, Mk, attn.wk, d, out=dkv_in, accumulate=acc_kv)
+        lin_bwd_x(dv, Mk, attn.wv, d, out=dkv_in, accumulate=True)
 
 
 def ffn_fwd(x, M, layer, p, rng):

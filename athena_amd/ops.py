@@ -29,6 +29,12 @@ def _ptr(t):
     return t.data_ptr()
 
 
+def _extent(t):
+    """Elements addressable from ``t``'s first element to the end of its storage (a column block of
+    a wider matrix is passed as a view plus the wide leading dimension)."""
+    return t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -109,11 +115,11 @@ def _fill_gemm_desc(d, a, b, c, M, N, K, trans_a=False, trans_b=False, lda=None,
     # bounds: the last row read/written must lie inside the tensors
     a_rows = K if trans_a else M
     b_rows = N if trans_b else K
-    if a.numel() < (a_rows - 1) * d.lda + (M if trans_a else K):
+    if _extent(a) < (a_rows - 1) * d.lda + (M if trans_a else K):
         raise RuntimeError("athena_amd.gemm: A too small for M=%d K=%d lda=%d" % (M, K, d.lda))
-    if b.numel() < (b_rows - 1) * d.ldb + (K if trans_b else N):
+    if _extent(b) < (b_rows - 1) * d.ldb + (K if trans_b else N):
         raise RuntimeError("athena_amd.gemm: B too small for N=%d K=%d ldb=%d" % (N, K, d.ldb))
-    if c.numel() < (M - 1) * d.ldc + N:
+    if _extent(c) < (M - 1) * d.ldc + N:
         raise RuntimeError("athena_amd.gemm: C too small for M=%d N=%d ldc=%d" % (M, N, d.ldc))
     if aux is not None and aux.numel() < (M - 1) * ldaux + N:
         raise RuntimeError("athena_amd.gemm: aux too small")

@@ -41,12 +41,12 @@ def make_positional_encoding(position, d_model):
 class Slot:
     """One registered variable: name, shape, offset into the flat buffers."""
     __slots__ = ("name", "shape", "numel", "offset", "trainable", "matrix", "sh_off", "sh_ld", "sht_off",
-                 "sht_ld", "init")
+                 "sht_ld", "init", "group")
 
     def __init__(self, name, shape, trainable, matrix, init):
         self.name, self.shape, self.trainable, self.matrix, self.init = name, tuple(shape), trainable, matrix, init
         self.numel = int(np.prod(shape))
-        self.offset = self.sh_off = self.sh_ld = self.sht_off = self.sht_ld = None
+        self.offset = self.sh_off = self.sh_ld = self.sht_off = self.sht_ld = self.group = None
 
 
 class ParamStore:
@@ -64,6 +64,7 @@ class ParamStore:
         self.collect_cuts = False
         self.cuts = []
         self._site = 0
+        self.shadow_groups = []
 
     # ---- registration (before finalize) -------------------------------------------------
     def register(self, name, shape, init, trainable=True, matrix=None):
@@ -76,6 +77,15 @@ class ParamStore:
         self.slots.append(s)
         self.by_name[name] = s
         return s
+
+    def group_shadows(self, names):
+        """Lay the bf16 shadows of several matrices [in, out_i] with equal ``in`` side by side: the
+        row-major copies form one [in, sum out_i] matrix and the transposed copies one
+        [sum out_i, in] matrix, so products with all of them can run as a single GEMM (each member
+        stays addressable as a column block / row block of the fused copy)."""
+        if self.finalized:
+            raise RuntimeError("ParamStore: group_shadows after finalize")
+        self.shadow_groups.append(list(names))
 
     def new_site(self):
         """A fresh dropout site id (distinct RNG stream per dropout layer)."""
@@ -109,16 +119,41 @@ class ParamStore:
         if self.compute_dtype == torch.bfloat16:
             soff = 0
             table, prefix = [], [0]
+            grouped = {}
+            for names in self.shadow_groups:
+                members = [self.by_name[n] for n in names]
+                r = members[0].matrix[0]
+                if any(m.matrix is None or m.matrix[0] != r or m.matrix[1] % 8 or r % 8 for m in members):
+                    raise ValueError("ParamStore: shadows %s cannot be grouped" % (names,))
+                total_c = sum(m.matrix[1] for m in members)
+                col = 0
+                for m in members:
+                    grouped[m.name] = (names[0], col, total_c)
+                    col += m.matrix[1]
+            group_base = {}
             for s in self.slots:
                 if s.matrix is None:
                     continue
                 r, c = s.matrix
-                s.sh_ld = ops.roundup(c, 8)
-                s.sht_ld = ops.roundup(r, 8)
-                s.sh_off = soff
-                soff += ops.roundup(r * s.sh_ld, ALIGN)
-                s.sht_off = soff
-                soff += ops.roundup(c * s.sht_ld, ALIGN)
+                if s.name in grouped:
+                    first, col, total_c = grouped[s.name]
+                    if first not in group_base:
+                        # members of a group are registered one after the other; space for all of them
+                        # is taken when the first one comes by
+                        group_base[first] = (soff, soff + r * total_c)
+                        soff += ops.roundup(2 * r * total_c, ALIGN)
+                    base, base_t = group_base[first]
+                    s.sh_ld, s.sht_ld = total_c, r
+                    s.sh_off = base + col
+                    s.sht_off = base_t + col * r
+                    s.group = (base, base_t, total_c)
+                else:
+                    s.sh_ld = ops.roundup(c, 8)
+                    s.sht_ld = ops.roundup(r, 8)
+                    s.sh_off = soff
+                    soff += ops.roundup(r * s.sh_ld, ALIGN)
+                    s.sht_off = soff
+                    soff += ops.roundup(c * s.sht_ld, ALIGN)
                 table += [s.offset, r, c, s.sh_off, s.sh_ld, s.sht_off, s.sht_ld]
                 prefix.append(prefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
             self.shadow = torch.zeros(max(soff, 8), dtype=torch.bfloat16, device=dev)
@@ -148,6 +183,15 @@ class ParamStore:
         a = self.shadow[s.sh_off:s.sh_off + r * s.sh_ld].view(r, s.sh_ld)
         b = self.shadow[s.sht_off:s.sht_off + c * s.sht_ld].view(c, s.sht_ld)
         return a, b
+
+    def group_shadow_views(self, name):
+        """(fused row-major copy [in, sum out_i], fused transposed copy [sum out_i, in]) of the
+        shadow group the matrix ``name`` belongs to."""
+        s = self.by_name[name]
+        base, base_t, total_c = s.group
+        r = s.matrix[0]
+        return (self.shadow[base:base + r * total_c].view(r, total_c),
+                self.shadow[base_t:base_t + r * total_c].view(total_c, r))
 
     def refresh_shadows(self, force=False):
         if self.shadow is None or self.sh_nmat == 0:

@@ -21,4 +21,6 @@ for M, N, K in [(1088, 256, 256), (8000, 256, 256), (8000, 256, 1024), (8000, 10
     print("M=%d N=%d K=%d  first block (10 ns units since entry):" % (M, N, K),
           ", ".join("%s +%d" % (names[i], s[i] - s[0]) for i in range(1, 6)),
           "| last block: entry +%d, stored +%d" % (s[8] - s[0], s[9] - s[0]),
-          "| quarter stamps", [s[i] - s[0] for i in range(10, 14)])
+          "| issue-done (before store ack) +%d" % (s[6] - s[0]),
+          "| pair iterations [loads issued, multiplied, set written, barrier, 2nd multiplied, 2nd barrier]:",
+          [[s[10 + 6 * h + j] - s[0] for j in range(6)] for h in range(min(8, (K // 64 + 1) // 2))])
