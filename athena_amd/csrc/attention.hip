@@ -341,10 +341,9 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
     dim3 gd((unsigned)((total + 255) / 256));
     if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo, lddq, lddk, lddv}, {q, k, v, out, dout, dq, dk_, dv})) {
         ATHENA_REQUIRE((long)B * h <= 65535, ATHENA_E_SHAPE, "athena_mha_bwd: B*h too large");
-        MHA_MFMA_DISPATCH(mha_delta_mfma_kernel, gd, (const bf16_t*)out, (const bf16_t*)dout, ldo, h, Tq, total, delta);
         const dim3 gq((Tq + AM_ROWS - 1) / AM_ROWS, B * h), gk((Tk + AM_ROWS - 1) / AM_ROWS, B * h);
         MHA_MFMA_DISPATCH(mha_bwd_dq_mfma_kernel, gq, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dq, lddq);
+                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dq, lddq);
         MHA_MFMA_DISPATCH(mha_bwd_dkv_mfma_kernel, gk, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
                           key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dk_,
                           (bf16_t*)dv, lddk, lddv);

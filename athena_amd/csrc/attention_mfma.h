@@ -218,38 +218,18 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------- backward
-// delta[b,h,i] = sum_c dout[b,i,h,c] * out[b,i,h,c]; one thread per (b, i, h)
-template <int DK>
-__global__ __launch_bounds__(256) void mha_delta_mfma_kernel(const bf16_t* __restrict__ out,
-                                                             const bf16_t* __restrict__ dout, int ldo, int h, int Tq,
-                                                             long total, float* __restrict__ delta) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // (b * Tq + i) * h + hh
-    if (idx >= total) return;
-    const int hh = (int)(idx % h);
-    const long bi = idx / h;
-    const int i = (int)(bi % Tq);
-    const long b = bi / Tq;
-    const long o = bi * ldo + hh * DK;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < DK; c += 8) {
-        const bf16x8_t a = *(const bf16x8_t*)(out + o + c);
-        const bf16x8_t d = *(const bf16x8_t*)(dout + o + c);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) s += (float)a[r] * (float)d[r];
-    }
-    delta[(b * h + hh) * Tq + i] = s;
-}
-
-// dQ: a wave owns 16 queries, keys/values streamed
+// dQ: a wave owns 16 queries, keys/values streamed.  delta[b,h,i] = sum_c dout[b,i,h,c] * out[b,i,h,c]
+// is worked out here from the dout fragments the kernel holds anyway (the four lanes of a query
+// cover its DK columns between them) and written out for the dK/dV kernel that follows.
 template <int DK>
 __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                               const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                               const uint8_t* __restrict__ key_mask, int causal, int h,
                                                               int Tq, int Tk, float scale,
+                                                              const bf16_t* __restrict__ out,
                                                               const bf16_t* __restrict__ dout, int ldo,
                                                               const float* __restrict__ lse,
-                                                              const float* __restrict__ delta, bf16_t* __restrict__ dq,
+                                                              float* __restrict__ delta, bf16_t* __restrict__ dq,
                                                               int lddq) {
     constexpr int KS = DK / 32, NT = DK / 16;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
@@ -263,13 +243,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
     const bool qok = qi < Tq;
 
     bf16x8_t qf[KS], dof[KS];
+    float del_i = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         qf[ks] = att_load8(q + (long)b * Tq * ldq + hh * DK, qi, Tq, ldq, 32 * ks + 8 * g);
         dof[ks] = att_load8(dout + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+        const bf16x8_t of = att_load8(out + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) del_i += (float)dof[ks][r] * (float)of[r];
     }
+    del_i += __shfl_xor(del_i, 16, 64);
+    del_i += __shfl_xor(del_i, 32, 64);
     const float lse_i = qok ? lse[((long)b * h + hh) * Tq + qi] : INFINITY;
-    const float del_i = qok ? delta[((long)b * h + hh) * Tq + qi] : 0.f;
+    if (qok && g == 0) delta[((long)b * h + hh) * Tq + qi] = del_i;
     f32x4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};

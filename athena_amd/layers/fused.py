@@ -234,6 +234,29 @@ class EncoderLayerFn(torch.autograd.Function):
         return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
+class _MemoryGrad:
+    """Gradient of the encoder output collected over the decoder layers that attend to it: the
+    first layer to run its backward pass stores into a shared buffer, the others add to it inside
+    their kernels, and the last one hands the buffer to autograd (the others return None), so no
+    separate additions are launched.  The bookkeeping hangs on the encoder-output tensor object
+    the layers of one forward pass share, and goes away with it."""
+
+    @staticmethod
+    def enter(memory):
+        slot = getattr(memory, "_athena_grad_slot", None)
+        if slot is None:
+            slot = {"users": 0, "buf": None}
+            memory._athena_grad_slot = slot
+        slot["users"] += 1
+        return slot
+
+    @staticmethod
+    def leave(slot):
+        """True if the caller is the last user (it returns the buffer)."""
+        slot["users"] -= 1
+        return slot["users"] == 0
+
+
 class DecoderLayerFn(torch.autograd.Function):
     """TransformerDecoderLayer.call (reference athena/layers/transformer.py:374-388)."""
 
@@ -257,6 +280,7 @@ class DecoderLayerFn(torch.autograd.Function):
                                                      layer.site_res3)
         ctx.layer, ctx.masks, ctx.p, ctx.shape = layer, (tgt_key_mask, mem_key_mask), p, (B, L, T, d)
         ctx.saved = (t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3)
+        ctx.mem_slot = _MemoryGrad.enter(memory) if ctx.needs_input_grad[1] else None
         return y3.view(B, L, d)
 
     @staticmethod
@@ -275,12 +299,21 @@ class DecoderLayerFn(torch.autograd.Function):
             ffn_bwd(df, y2, M, layer, s_ffn, p, rng, d_y2)
             d_y1, da2 = ops.add_layernorm_bwd(d_y2, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
                                               layer.norm2.gamma.grad, layer.norm2.beta.grad)
-            dmem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
-            mha_block_bwd(da2, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, False)
+            slot = ctx.mem_slot
+            if slot is None:
+                dmem, acc_mem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device), False
+            else:
+                acc_mem = slot["buf"] is not None
+                if not acc_mem:
+                    slot["buf"] = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
+                dmem = slot["buf"]
+            mha_block_bwd(da2, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, acc_mem)
+            if slot is not None and not _MemoryGrad.leave(slot):
+                dmem = None
             dtgt, da1 = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
                                               layer.norm1.gamma.grad, layer.norm1.beta.grad)
             mha_block_bwd(da1, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True)
-        return (dtgt.view(B, L, d), dmem.view(B, T, d), None, None, None, None) + \
+        return (dtgt.view(B, L, d), None if dmem is None else dmem.view(B, T, d), None, None, None, None) + \
             (None,) * (len(ctx.needs_input_grad) - 6)
 
 

@@ -147,8 +147,14 @@ class SpeechTransformer(BaseModel):
 
     def compute_logit_length(self, samples):
         """ceil(ceil(len/2)/2) (speech_transformer.py:156-162)."""
-        n = samples["input_length"].to(torch.int32)
-        return (((n + 1) // 2) + 1) // 2
+        src = samples["input_length"]
+        hit = getattr(self, "_logit_length_cache", None)
+        if hit is not None and hit[0] is src and hit[1] == src._version:
+            return hit[2]        # asked for again by the loss with the same batch
+        n = src.to(torch.int32)
+        out = (((n + 1) // 2) + 1) // 2
+        self._logit_length_cache = (src, src._version, out)
+        return out
 
     def restore_from_pretrained_model(self, pretrained_model, model_type=""):
         if model_type == "":
