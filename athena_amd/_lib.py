@@ -53,6 +53,8 @@ _SIGNATURES = {
     "athena_add_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_uint32, c_int,
                                          _P, _P, _P, _P, _P, c_int64, _S]),
     "athena_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
+    "athena_add_layernorm_bwd_slabs": (c_int, [c_int, c_int]),
+    "athena_ln_fold_batched": (c_int, [_P, c_int, c_int, _S]),
     "athena_mha_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_float, _P, c_int, _P, _S]),
     "athena_mha_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,

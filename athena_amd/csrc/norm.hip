@@ -374,6 +374,55 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ 
     }
 }
 
+// the same fold for several LayerNorms in one launch (blockIdx.y picks the item)
+struct LnFoldItem {
+    const float* slabs;
+    float* dgamma;
+    float* dbeta;
+    int32_t nblk;
+    int32_t d;
+};
+static_assert(sizeof(LnFoldItem) == sizeof(athena_ln_fold_item), "LnFoldItem mirrors athena_ln_fold_item");
+
+__global__ __launch_bounds__(256) void ln_fold_batched_kernel(const LnFoldItem* __restrict__ items) {
+    __shared__ float red[16][17];
+    const LnFoldItem it = items[blockIdx.y];
+    const int part = threadIdx.x >> 4, le = threadIdx.x & 15;
+    const int e = blockIdx.x * 16 + le;
+    const int d = it.d, nblk = it.nblk;
+    if (blockIdx.x * 16 >= 2 * d) return;            // uniform per workgroup
+    const long stride = 2L * d;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < 2 * d) {
+        int b = part;
+        for (; b + 48 < nblk; b += 64) {
+            a0 += it.slabs[(long)b * stride + e];
+            a1 += it.slabs[(long)(b + 16) * stride + e];
+            a2 += it.slabs[(long)(b + 32) * stride + e];
+            a3 += it.slabs[(long)(b + 48) * stride + e];
+        }
+        for (; b < nblk; b += 16) a0 += it.slabs[(long)b * stride + e];
+    }
+    red[part][le] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && e < 2 * d) {
+        float t = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < 16; ++p2) t += red[p2][le];
+        if (e < d) it.dgamma[e] = t;
+        else it.dbeta[e - d] = t;
+    }
+}
+
+extern "C" int athena_ln_fold_batched(const athena_ln_fold_item* items, int count, int max_d,
+                                      athena_stream_t stream) {
+    ATHENA_REQUIRE(items && count > 0 && count <= 65535 && max_d > 0, ATHENA_E_SHAPE, "athena_ln_fold_batched: bad arguments");
+    hipLaunchKernelGGL(ln_fold_batched_kernel, dim3((2 * max_d + 15) / 16, count), dim3(256), 0, (hipStream_t)stream,
+                       (const LnFoldItem*)items);
+    ATHENA_CHECK_LAUNCH("athena_ln_fold_batched");
+    return ATHENA_OK;
+}
+
 static inline int ln_group(int d) {
     int G = 1;
     while (G * 8 < d) G <<= 1;
@@ -429,6 +478,11 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
                          int rows, int d, uint32_t th, float ds, const uint64_t* rng_state, uint32_t site,
                          int acc, void* da, void* db, float* dgamma, float* dbeta, float* slabs,
                          hipStream_t stream) {
+    if (!dgamma) {
+        // partial sums only: the caller folds the slabs later (athena_ln_fold_batched)
+        ATHENA_REQUIRE(slabs && ln_vec_ok(d, {dy, z, gamma, da, db}), ATHENA_E_UNSUPPORTED,
+                       "add_layernorm_bwd: deferred column sums need the workspace and d %% 8 == 0, d <= 512");
+    }
     if (ln_vec_ok(d, {dy, z, gamma, da, db})) {
         const int nblk = (rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK;
         if (!slabs) {
@@ -450,7 +504,7 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
             default: LNV_BWD(64); break;
         }
 #undef LNV_BWD
-        if (slabs)
+        if (slabs && dgamma)
             hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, stream, (const float*)slabs, nblk, d,
                                dgamma, dbeta);
         ATHENA_CHECK_LAUNCH("add_layernorm_bwd");
@@ -477,6 +531,11 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
     return ATHENA_OK;
 }
 
+extern "C" int athena_add_layernorm_bwd_slabs(int rows, int d) {
+    if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 512) return 0;
+    return (rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK;
+}
+
 extern "C" int64_t athena_add_layernorm_bwd_workspace_bytes(int rows, int d) {
     if (rows <= 0 || d <= 0) return 0;
     return (int64_t)sizeof(float) * ((rows + LNV_ROWS_PER_BLOCK - 1) / LNV_ROWS_PER_BLOCK) * 2 * d;
@@ -487,7 +546,7 @@ extern "C" int athena_add_layernorm_bwd(const void* dy, const void* z, const flo
                                         const uint64_t* rng_state, uint32_t rng_site, int accumulate_da, void* da,
                                         void* db, float* dgamma, float* dbeta, void* workspace,
                                         int64_t workspace_bytes, athena_stream_t stream) {
-    ATHENA_REQUIRE(dy && z && mean && rstd && gamma && da && dgamma && dbeta, ATHENA_E_SHAPE, "add_layernorm_bwd: null operand");
+    ATHENA_REQUIRE(dy && z && mean && rstd && gamma && da && ((dgamma && dbeta) || (!dgamma && !dbeta)), ATHENA_E_SHAPE, "add_layernorm_bwd: null operand");
     ATHENA_REQUIRE(rows > 0 && d > 0 && d <= 2048, ATHENA_E_SHAPE, "add_layernorm_bwd: bad shape rows=%d d=%d (d <= 2048)", rows, d);
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && db), ATHENA_E_SHAPE, "add_layernorm_bwd: dropout args");
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;

@@ -183,19 +183,87 @@ def add_layernorm_fwd(a, b, gamma, beta, eps, drop_p, rng_state, site):
     return z, y, mean, rstd
 
 
+class _LnFolds:
+    """Column sums (dgamma, dbeta) of the LayerNorm gradients of one backward pass, folded together.
+
+    Inside a backward pass every ``add_layernorm_bwd`` leaves its per-workgroup partial sums in its
+    own piece of an arena, and one launch at the end of the pass (an end-of-backward callback of the
+    autograd engine) adds them all up.  The table of pieces handed to that launch repeats from step
+    to step, so it is built once per distinct sequence; a new one is uploaded from pinned memory
+    with an asynchronous copy, which a HIP-graph capture can record."""
+    ARENA_BYTES = 128 << 20
+    state = {}
+
+    @classmethod
+    def get(cls, device):
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls.state.get(index)
+        if st is None:
+            st = cls.state[index] = {"index": index, "arena": None, "cursor": 0, "items": [], "queued": False,
+                                     "tables": {}}
+        return st
+
+    @classmethod
+    def reserve(cls, device, nslab, d, dgamma, dbeta):
+        """Arena piece (tensor view) for one deferred call, or None when folding cannot be deferred
+        (not inside a backward pass, or the arena is full)."""
+        st = cls.get(device)
+        need = nslab * 2 * d
+        if st["arena"] is None:
+            st["arena"] = torch.empty(cls.ARENA_BYTES // 4, dtype=torch.float32,
+                                      device=torch.device("cuda", st["index"]))
+        if st["cursor"] + need > st["arena"].numel():
+            return None
+        if not st["queued"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: cls.flush(st))
+            except RuntimeError:
+                return None
+            st["queued"] = True
+        piece = st["arena"][st["cursor"]:st["cursor"] + need]
+        st["items"].append((piece.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), nslab, d))
+        st["cursor"] += (need + 63) // 64 * 64
+        return piece
+
+    @classmethod
+    def flush(cls, st):
+        items, st["items"], st["cursor"], st["queued"] = st["items"], [], 0, False
+        if not items:
+            return
+        key = tuple(items)
+        table = st["tables"].get(key)
+        if table is None:
+            import struct
+            raw = b"".join(struct.pack("<QQQii", *it) for it in items)
+            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+            devt = torch.empty(len(raw), dtype=torch.uint8, device=torch.device("cuda", st["index"]))
+            devt.copy_(host, non_blocking=True)
+            table = st["tables"][key] = (devt, host)
+        lib = _lib.load()
+        with torch.cuda.device(st["index"]):
+            _lib.check(lib.athena_ln_fold_batched(table[0].data_ptr(), len(items), max(it[4] for it in items),
+                                                  _stream()), "athena_ln_fold_batched")
+
+
 def add_layernorm_bwd(dy, z, mean, rstd, gamma, drop_p, rng_state, site, dgamma, dbeta, need_db=True):
-    """Returns (da, db).  db is da itself when there is no dropout."""
+    """Returns (da, db).  db is da itself when there is no dropout.  Inside a backward pass dgamma and
+    dbeta are complete when the pass ends (see ``_LnFolds``), otherwise on return."""
     lib = _lib.load()
     rows, d, ld = _rows2d(z)
     if not dy.is_contiguous() or dy.shape != z.shape or ld != d:
         raise RuntimeError("athena_amd.add_layernorm_bwd: operands must be contiguous and equal-shaped")
     da = torch.empty_like(z)
     db = torch.empty_like(z) if (drop_p > 0.0 and need_db) else None
-    ws = small_workspace(z.device)
+    nslab = lib.athena_add_layernorm_bwd_slabs(rows, d)
+    piece = _LnFolds.reserve(z.device, nslab, d, dgamma, dbeta) if nslab > 0 else None
+    if piece is not None:
+        ws_ptr, ws_bytes, pg, pb = piece.data_ptr(), piece.numel() * 4, None, None
+    else:
+        ws = small_workspace(z.device)
+        ws_ptr, ws_bytes, pg, pb = ws.data_ptr(), ws.numel(), _ptr(dgamma), _ptr(dbeta)
     _lib.check(lib.athena_add_layernorm_bwd(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), rows, d,
                                             dt(z), drop_p if db is not None else 0.0, _ptr(rng_state), site, 0,
-                                            _ptr(da), _ptr(db), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), ws.numel(),
-                                            _stream()),
+                                            _ptr(da), _ptr(db), pg, pb, ws_ptr, ws_bytes, _stream()),
                "athena_add_layernorm_bwd")
     return da, (db if db is not None else da)
 
