@@ -81,7 +81,7 @@ _SIGNATURES = {
                                  _P, _S]),
     "athena_embed_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32, _P, _S]),
     "athena_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "athena_ctc_loss_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+    "athena_ctc_loss_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                     c_size_t, _S]),
     "athena_ctc_loss_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float,
                                     _P, c_int, _P, c_size_t, _S]),

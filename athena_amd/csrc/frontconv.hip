@@ -204,6 +204,12 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
     }
 }
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// channels per thread of the backward reduction for a layer of C channels (16 for wide layers: the
+// nine taps of a pixel are then fetched and bounds-checked once per 16 channels)
+static inline int fc_cpt(int C) { return (C % 16 == 0 && C >= 128 && 256 % (C / 16) == 0) ? 16 : 8; }
+
 static int fc_check(const char* name, int B, int H, int W, int C, int dtype) {
     ATHENA_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, ATHENA_E_SHAPE, "%s: bad shape", name);
     ATHENA_REQUIRE((long)B * H * W < (1L << 31), ATHENA_E_SHAPE, "%s: input too large", name);
@@ -242,20 +248,21 @@ extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, c
 // ---------------------------------------------------------------- backward
 #define FC_BWD_BLOCKS 512
 // partial[blk][t][c] (t < 9: sum a g; t == 9: sum g), fp32, one slab per workgroup
-template <typename T>
+template <typename T, int CPT>
 __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restrict__ in, const T* __restrict__ g,
                                                             const T* __restrict__ act, int B, int H, int W, int C,
                                                             int Ho, int Wo, int ph, int pw,
                                                             float* __restrict__ partial) {
-    extern __shared__ float red[];                   // [4 waves][(FC_K + 1)][C] (C <= 512), else [(FC_K + 1)][C]
-    const int cpr = C / 8;
+    extern __shared__ float red[];                   // [4 waves][(FC_K + 1)][C] (planes), else [(FC_K + 1)][C]
+    constexpr int NP = CPT / 2;
+    const int cpr = C / CPT;
     const int chunk = threadIdx.x % cpr, slot = threadIdx.x / cpr, slots = 256 / cpr;
-    const int c0 = chunk * 8;
-    float acc[FC_K + 1][8];
+    const int c0 = chunk * CPT;
+    f32x2_t acc[FC_K + 1][NP];
 #pragma unroll
     for (int t = 0; t <= FC_K; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+        for (int i = 0; i < NP; ++i) acc[t][i] = (f32x2_t){0.f, 0.f};
     const bool planes = cpr <= 64;                   // fold by shuffles + one LDS plane per wave
     if (!planes) {
         for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
@@ -265,36 +272,41 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
     for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
         const int q = pix / Wo, wo = pix - q * Wo;
         const int b = q / Ho, ho = q - b * Ho;
-        float a[FC_K], gv[8];
+        float a[FC_K], gv[CPT];
         fc_taps(in, H, W, b, ho, wo, ph, pw, a);
         if (sizeof(T) == 2) {
-            const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + (long)pix * C + c0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) gv[i] = (float)h[i];
-            if (act) {       // g is the gradient w.r.t. the relu6 output: apply the gate read off the activation
-                const bf16x8_t y = *(const bf16x8_t*)((const bf16_t*)act + (long)pix * C + c0);
+            for (int j = 0; j < CPT; j += 8) {
+                const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + (long)pix * C + c0 + j);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gv[i] = ((float)y[i] > 0.f && (float)y[i] < 6.f) ? gv[i] : 0.f;
+                for (int i = 0; i < 8; ++i) gv[j + i] = (float)h[i];
+                if (act) {   // g is the gradient w.r.t. the relu6 output: apply the gate read off the activation
+                    const bf16x8_t y = *(const bf16x8_t*)((const bf16_t*)act + (long)pix * C + c0 + j);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gv[j + i] = ((float)y[i] > 0.f && (float)y[i] < 6.f) ? gv[j + i] : 0.f;
+                }
             }
         } else {
-            const float* gp = (const float*)g + (long)pix * C + c0;
-            const float4 h0 = *(const float4*)gp, h1 = *(const float4*)(gp + 4);
-            gv[0] = h0.x; gv[1] = h0.y; gv[2] = h0.z; gv[3] = h0.w;
-            gv[4] = h1.x; gv[5] = h1.y; gv[6] = h1.z; gv[7] = h1.w;
-            if (act) {
-                const float* yp = (const float*)act + (long)pix * C + c0;
-                const float4 y0 = *(const float4*)yp, y1 = *(const float4*)(yp + 4);
-                const float y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gv[i] = (y[i] > 0.f && y[i] < 6.f) ? gv[i] : 0.f;
+            for (int j = 0; j < CPT; j += 4) {
+                const float4 h = *(const float4*)((const float*)g + (long)pix * C + c0 + j);
+                gv[j] = h.x; gv[j + 1] = h.y; gv[j + 2] = h.z; gv[j + 3] = h.w;
+                if (act) {
+                    const float4 y4 = *(const float4*)((const float*)act + (long)pix * C + c0 + j);
+                    const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gv[j + i] = (y[i] > 0.f && y[i] < 6.f) ? gv[j + i] : 0.f;
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < FC_K; ++t)
+        for (int i = 0; i < NP; ++i) {
+            const f32x2_t g2 = (f32x2_t){gv[2 * i], gv[2 * i + 1]};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[t][i] = fmaf(a[t], gv[i], acc[t][i]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[FC_K][i] += gv[i];
+            for (int t = 0; t < FC_K; ++t)
+                acc[t][i] = __builtin_elementwise_fma((f32x2_t){a[t], a[t]}, g2, acc[t][i]);
+            acc[FC_K][i] += g2;
+        }
     }
     // fold the pixel slots of the workgroup, then store the slab
     float* dst = partial + (long)blockIdx.x * (FC_K + 1) * C;
@@ -305,8 +317,8 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t <= FC_K; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = acc[t][i];
+            for (int i = 0; i < CPT; ++i) {
+                float v = acc[t][i / 2][i % 2];
                 for (int o = cpr; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
                 if (lane < cpr) red[w * nent + t * C + c0 + i] = v;
             }
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t <= FC_K; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&red[t * C + c0 + i], acc[t][i]);
+        for (int i = 0; i < CPT; ++i) atomicAdd(&red[t * C + c0 + i], acc[t][i / 2][i % 2]);
     __syncthreads();
     for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) dst[i] = red[i];
 }
@@ -396,18 +408,24 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* r
     fc_same_pad(H, &Ho, &ph);
     fc_same_pad(W, &Wo, &pw);
     const long npix = (long)B * Ho * Wo;
-    const int slots = 256 / (Cout / 8);
+    const int cpt = fc_cpt(Cout);
+    const int slots = 256 / (Cout / cpt);
     long blocks = (npix + slots - 1) / slots;
     if (blocks > FC_BWD_BLOCKS) blocks = FC_BWD_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
-    const size_t shm = sizeof(float) * (FC_K + 1) * Cout * (Cout / 8 <= 64 ? 4 : 1);
+    const size_t shm = sizeof(float) * (FC_K + 1) * Cout * (Cout / cpt <= 64 ? 4 : 1);
     ATHENA_REQUIRE(!relu6_out || athena_aligned16(relu6_out), ATHENA_E_ALIGN, "athena_conv1_bn_bwd: relu6_out alignment");
-    if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(fc_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const bf16_t*)g,
-                           (const bf16_t*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
-    else
-        hipLaunchKernelGGL(fc_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), shm, s, in, (const float*)g,
-                           (const float*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace);
+#define FC_BWD(TT, CC)                                                                                          \
+    hipLaunchKernelGGL((fc_bwd_reduce_kernel<TT, CC>), dim3((unsigned)blocks), dim3(256), shm, s, in, (const TT*)g, \
+                       (const TT*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace)
+    if (dtype == ATHENA_BF16) {
+        if (cpt == 16) FC_BWD(bf16_t, 16);
+        else FC_BWD(bf16_t, 8);
+    } else {
+        if (cpt == 16) FC_BWD(float, 16);
+        else FC_BWD(float, 8);
+    }
+#undef FC_BWD
     const int nent = (FC_K + 1) * Cout;
     double* tot = (double*)((char*)workspace + sizeof(float) * (size_t)FC_BWD_BLOCKS * nent);   // 8-byte aligned
     hipLaunchKernelGGL(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,

@@ -112,6 +112,57 @@ __device__ __forceinline__ void row_max_sum<float>(const float* __restrict__ row
     m_out = gm;
 }
 
+// the same online (max, sum) that also tracks the first column holding the row maximum (the greedy
+// CTC path of the accuracy metric, reference athena/metrics.py:121-132, for no extra pass over the row)
+template <typename T>
+__device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V, float& m_out, float& s_out,
+                                                int& arg_out, float* red) {
+    float m = -INFINITY, s = 0.f;
+    int idx = 0x7fffffff;
+    if constexpr (sizeof(T) == 4) {
+        const int V4 = V & ~3;
+        for (int c = threadIdx.x * 4; c < V4; c += blockDim.x * 4) {
+            const float4 x = *(const float4*)((const float*)row + c);
+            const float mx = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+            if (mx > m) {
+                s *= __expf(m - mx);
+                m = mx;
+                idx = c + (x.x == mx ? 0 : x.y == mx ? 1 : x.z == mx ? 2 : 3);
+            }
+            s += __expf(x.x - m) + __expf(x.y - m) + __expf(x.z - m) + __expf(x.w - m);
+        }
+        for (int c = V4 + threadIdx.x; c < V; c += blockDim.x) {
+            const float x = ((const float*)row)[c];
+            if (x > m) {
+                s = s * __expf(m - x) + 1.f;
+                m = x;
+                idx = c;
+            } else {
+                s += __expf(x - m);
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < V; c += blockDim.x) {
+            const float x = to_f32<T>(row[c]);
+            if (x > m) {
+                s = s * __expf(m - x) + 1.f;
+                m = x;
+                idx = c;
+            } else {
+                s += __expf(x - m);
+            }
+        }
+    }
+    const float gm = block_max(m, red);
+    const float contrib = (m == -INFINITY) ? 0.f : s * __expf(m - gm);
+    s_out = block_sum(contrib, red);
+    // smallest column among the threads that saw the maximum (column indices are exact in fp32)
+    const float cand = (m == gm && idx != 0x7fffffff) ? -(float)idx : -INFINITY;
+    const float best = block_max(cand, red);
+    arg_out = best == -INFINITY ? 0 : (int)(-best);
+    m_out = gm;
+}
+
 // ---------------------------------------------------------------- lattice arithmetic (log2 domain)
 // log2(2^a + 2^b + 2^c) and log2(2^a + 2^b) on the raw exp2 / log2 units: the largest term
 // contributes exactly 1, so one exponential fewer than terms
@@ -187,7 +238,8 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
                                                       const int32_t* __restrict__ logit_len, int B, int T_, int V,
                                                       int U, int blank, float* __restrict__ lse,
                                                       float* __restrict__ nrm, float* __restrict__ alpha,
-                                                      float* __restrict__ beta, double* __restrict__ ll) {
+                                                      float* __restrict__ beta, double* __restrict__ ll,
+                                                      int32_t* __restrict__ argmax) {
     __shared__ float red[32];
     if ((int)blockIdx.x >= B) {
         const int row = blockIdx.x - B;
@@ -195,11 +247,14 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
         if (t >= logit_len[b]) return;
         const T* lr = logits + (long)row * ldl;
         float m, s;
-        row_max_sum<T>(lr, V, m, s, red);
+        int am = 0;
+        if (argmax) row_max_sum_arg<T>(lr, V, m, s, am, red);      // uniform branch
+        else row_max_sum<T>(lr, V, m, s, red);
         if (threadIdx.x == 0) {
             const float ls = __logf(s);
             lse[row] = m + ls;
             nrm[row] = (m - to_f32<T>(lr[blank])) + ls;
+            if (argmax) argmax[row] = am;
         }
         return;
     }
@@ -535,16 +590,16 @@ static int ctc_check(const char* name, const void* logits, int dtype, int ldl, i
 template <typename T, int R>
 static void launch_ctc_fwd(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
                            const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
-                           hipStream_t s) {
+                           int32_t* argmax, hipStream_t s) {
     hipLaunchKernelGGL((ctc_fwd_kernel<T, R>), dim3(B + B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len,
-                       logit_len, B, Tn, V, U, blank, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll);
+                       logit_len, B, Tn, V, U, blank, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll, argmax);
 }
 
 template <typename T>
 static void dispatch_ctc_fwd(int R, const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
                              const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
-                             hipStream_t s) {
-#define CTC_FWD(N) launch_ctc_fwd<T, N>(logits, ldl, labels, label_len, logit_len, B, Tn, V, U, blank, ws, s)
+                             int32_t* argmax, hipStream_t s) {
+#define CTC_FWD(N) launch_ctc_fwd<T, N>(logits, ldl, labels, label_len, logit_len, B, Tn, V, U, blank, ws, argmax, s)
     switch (R) {
         case 1: CTC_FWD(1); break;
         case 2: CTC_FWD(2); break;
@@ -560,7 +615,7 @@ static void dispatch_ctc_fwd(int R, const T* logits, int ldl, const int32_t* lab
 
 extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
                                    const int32_t* label_len, const int32_t* logit_len, int B, int T, int V, int U,
-                                   int blank, float* loss, void* workspace, size_t workspace_bytes,
+                                   int blank, float* loss, int32_t* argmax, void* workspace, size_t workspace_bytes,
                                    athena_stream_t stream) {
     int rc = ctc_check("athena_ctc_loss_fwd", logits, logits_dtype, ldl, B, T, V, U, blank, workspace, workspace_bytes);
     if (rc) return rc;
@@ -570,9 +625,9 @@ extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl
     hipStream_t s = (hipStream_t)stream;
     const int R = ctc_launch_r(2 * U + 1);
     if (logits_dtype == ATHENA_BF16)
-        dispatch_ctc_fwd<bf16_t>(R, (const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, s);
+        dispatch_ctc_fwd<bf16_t>(R, (const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
     else
-        dispatch_ctc_fwd<float>(R, (const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, s);
+        dispatch_ctc_fwd<float>(R, (const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
     hipLaunchKernelGGL(ctc_finish_kernel, dim3(B), dim3(64), 0, s, label_len, logit_len, T, ws.nrm, ws.ll, loss);
     ATHENA_CHECK_LAUNCH("athena_ctc_loss_fwd");
     return ATHENA_OK;

@@ -358,9 +358,9 @@ class DenseFn(torch.autograd.Function):
         N = dense.out_features
         Np = ops.roundup(N, 8)
         x2 = x.reshape(B * T, K)
+        # the padding columns [N, Np) stay unwritten: nothing reads them (the returned view ends at N,
+        # the loss kernels take V columns of each row)
         out, _ = lin_fwd(x2, B * T, dense, out_dtype=torch.float32, ldc=Np)
-        if Np != N:
-            out[:, N:].zero_()
         ctx.dense, ctx.x2, ctx.shape = dense, x2, (B, T, K, N, Np)
         return out.view(B, T, Np)[..., :N]
 

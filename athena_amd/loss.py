@@ -34,16 +34,19 @@ class _CTCLossFn(torch.autograd.Function):
         logit_len = logit_len.to(torch.int32).contiguous()
         ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=logits.device)
         per = torch.empty(B, dtype=torch.float32, device=logits.device)
-        ops.ctc_loss_fwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws)
+        # the pass over the rows also leaves the per-frame arg-max (zero beyond logit_length)
+        best = torch.zeros(B * T, dtype=torch.int32, device=logits.device)
+        ops.ctc_loss_fwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws, argmax=best)
         out = torch.empty(1, dtype=torch.float32, device=logits.device)
         ops.group_sum(per, 1, B, 1.0 / B, out)          # tf.reduce_mean over the batch
         ctx.saved = (src, ldl, labels, label_len, logit_len, ws)
         ctx.dims = (B, T, V, U, blank)
         ctx.per_sample = per
-        return out.view(())
+        ctx.mark_non_differentiable(best)
+        return out.view(()), best
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, _gbest=None):
         src, ldl, labels, label_len, logit_len, ws = ctx.saved
         B, T, V, U, blank = ctx.dims
         gs = gout.to(torch.float32).reshape(1).contiguous()
@@ -68,7 +71,10 @@ class CTCLoss:
         assert logit_length is not None
         V = logits.shape[-1]
         blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
-        return _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank)
+        loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank)
+        # CTCAccuracy on the same logits and lengths picks this up instead of a second pass over them
+        logits._athena_ctc_argmax = (best, logits._version, logit_length)
+        return loss
 
 
 class _CELossFn(torch.autograd.Function):

@@ -177,9 +177,13 @@ class CTCAccuracy(CharactorAccuracy):
         if T <= samples["output"].shape[1] + 1:
             logging.warning("the length of logits is shorter than that of labels")
             return
-        _, _, ld = ops._rows2d(logits)
-        pred = torch.empty(B * T, dtype=torch.int32, device=logits.device)
-        ops.argmax_rows(logits.detach(), ld, B * T, V, pred)
+        hit = getattr(logits, "_athena_ctc_argmax", None)
+        if hit is not None and hit[1] == logits._version and hit[2] is logit_length and hit[0].numel() == B * T:
+            pred = hit[0]        # left by the CTC loss kernel for the frames inside logit_length
+        else:
+            _, _, ld = ops._rows2d(logits)
+            pred = torch.empty(B * T, dtype=torch.int32, device=logits.device)
+            ops.argmax_rows(logits.detach(), ld, B * T, V, pred)
 
         def score(pred_h, len_h, labels_h):
             best = pred_h.view(B, T).tolist()

@@ -77,7 +77,11 @@ class MtlTransformerCtc(BaseModel):
         self.metric(ctc_logits, samples, logit_length)
         main_loss, metrics = self.model.get_loss(attention_logits, samples, training=training)
         mtl_weight = self.hparams.mtl_weight
-        loss = mtl_weight * main_loss + (1.0 - mtl_weight) * extra_loss
+        if isinstance(main_loss, torch.Tensor) and isinstance(extra_loss, torch.Tensor):
+            # mtl_weight * main + (1 - mtl_weight) * extra as one kernel (mtl_seq2seq.py:95)
+            loss = torch.lerp(extra_loss, main_loss, float(mtl_weight))
+        else:
+            loss = mtl_weight * main_loss + (1.0 - mtl_weight) * extra_loss
         metrics[self.metric.name] = LazyMetric(self.metric)
         return loss, metrics
 

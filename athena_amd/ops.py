@@ -447,15 +447,18 @@ def ctc_workspace_bytes(B, T, U):
     return int(_lib.load().athena_ctc_workspace_bytes(B, T, U))
 
 
-def ctc_loss_fwd(logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, loss, workspace):
+def ctc_loss_fwd(logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, loss, workspace, argmax=None):
+    """``argmax`` (optional int32 [B*T]) receives the first arg-max class of every row inside logit_len."""
     lib = _lib.load()
+    if argmax is not None and (argmax.dtype != torch.int32 or argmax.numel() < B * T or not argmax.is_contiguous()):
+        raise RuntimeError("athena_amd.ctc_loss: argmax must be contiguous int32 [B*T]")
     for t_ in (labels, label_len, logit_len):
         if t_.dtype != torch.int32 or not t_.is_contiguous():
             raise RuntimeError("athena_amd.ctc_loss: labels and lengths must be contiguous int32")
     if labels.numel() != B * U or label_len.numel() != B or logit_len.numel() != B or loss.numel() != B:
         raise RuntimeError("athena_amd.ctc_loss: bad label shapes")
     _lib.check(lib.athena_ctc_loss_fwd(_ptr(logits), dt(logits), ldl, _ptr(labels), _ptr(label_len),
-                                       _ptr(logit_len), B, T, V, U, blank, _ptr(loss), _ptr(workspace),
+                                       _ptr(logit_len), B, T, V, U, blank, _ptr(loss), _ptr(argmax), _ptr(workspace),
                                        workspace.numel() * workspace.element_size(), _stream()),
                "athena_ctc_loss_fwd")
 

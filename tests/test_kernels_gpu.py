@@ -536,8 +536,16 @@ def test_ctc_loss_and_grad_fp32(ops, B, T, V, U):
     per = torch.empty(B, dtype=torch.float32, device=dev())
     lab_d = torch.from_numpy(labels).to(dev())
     ll_d, tl_d = torch.from_numpy(llen).to(dev()), torch.from_numpy(tlen).to(dev())
-    ops.ctc_loss_fwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, per, ws)
+    best = torch.full((B * T,), -7, dtype=torch.int32, device=dev())
+    ops.ctc_loss_fwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, per, ws, argmax=best)
     assert_close(per, loss_ref, 1e-5, "ctc loss")
+    # the per-frame arg-max that the same pass leaves for the accuracy metric: exact inside
+    # logit_length, untouched beyond
+    want = lt.argmax(-1)
+    got = best.view(B, T).cpu()
+    for b in range(B):
+        assert got[b, :tlen[b]].tolist() == want[b, :tlen[b]].tolist()
+        assert (got[b, tlen[b]:] == -7).all()
     grad = torch.full((B, T, ldl), float("nan"), dtype=torch.float32, device=dev())
     gs = torch.tensor([0.5], dtype=torch.float32, device=dev())
     ops.ctc_loss_bwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, gs, 2.0 / B, grad, ws)
