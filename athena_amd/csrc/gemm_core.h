@@ -209,6 +209,11 @@ struct GemmProblem {
     // optional output row remap for strided scatter of C rows (ConvDgrad): row m -> c_row(m)
     int crow_mode;           // 0: identity; 1: parity-class scatter
     int cr_Ah, cr_Aw, cr_H, cr_W, cr_h0, cr_w0;   // crow = ((b*H + 2*ah+h0)*W + 2*aw+w0)
+    // XCD-aware tile order of a 1-D launch (0 = off, the grid is (tiles_m, tiles_n, z)): workgroup ids
+    // go round-robin over the 8 XCDs, so id -> (XCD = id % 8, position j = id / 8 on that XCD); the
+    // xcd_tn column tiles of one row tile take consecutive positions of one XCD and find the A rows
+    // their neighbour just fetched in that XCD's L2
+    int xcd_tn, xcd_tm;
 };
 
 template <class AMap>
@@ -721,7 +726,14 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
 
 template <class AMap, bool TA, bool TB, int WT>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmProblem<AMap> p) {
-    gemm_mfma_body<AMap, TA, TB, WT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_tn > 0) {
+        const int j = blockIdx.x >> 3;
+        by = j % p.xcd_tn;
+        bx = (j / p.xcd_tn) * 8 + (blockIdx.x & 7);
+        if (bx >= p.xcd_tm) return;                 // whole workgroup: the grid is rounded up to 8 row tiles
+    }
+    gemm_mfma_body<AMap, TA, TB, WT>(p, bx, by, blockIdx.z);
 }
 
 // Several independent problems (same operand layouts) in one launch: the workgroups of all
@@ -978,11 +990,21 @@ static inline long gemm_tiles(int M, int N, int bt) { return (long)((M + bt - 1)
 template <class AMap, int WT>
 static void launch_mfma(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_t stream) {
     constexpr int BT = 32 * WT;
-    dim3 grid((p.M + BT - 1) / BT, (p.N + BT - 1) / BT, p.split_k * (p.zbatch > 1 ? p.zbatch : 1));
-    if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, true, WT>), grid, dim3(256), 0, stream, p);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, false, WT>), grid, dim3(256), 0, stream, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, false, WT>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, true, WT>), grid, dim3(256), 0, stream, p);
+    const int tm = (p.M + BT - 1) / BT, tn = (p.N + BT - 1) / BT;
+    const int gz = p.split_k * (p.zbatch > 1 ? p.zbatch : 1);
+    dim3 grid(tm, tn, gz);
+    GemmProblem<AMap> q = p;
+    q.xcd_tn = 0;
+    q.xcd_tm = tm;
+    if (gz == 1 && tn >= 2 && tn <= 16 && tm >= 32) {
+        // tall output with a few column tiles: the A operand dominates the traffic
+        q.xcd_tn = tn;
+        grid = dim3((unsigned)((tm + 7) / 8 * 8 * tn), 1, 1);
+    }
+    if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, true, WT>), grid, dim3(256), 0, stream, q);
+    else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, false, WT>), grid, dim3(256), 0, stream, q);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, false, WT>), grid, dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, true, WT>), grid, dim3(256), 0, stream, q);
 }
 
 // Tile edge and split-K factor for an M x N output with ``k_elems`` contraction elements and
