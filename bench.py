@@ -188,6 +188,21 @@ def cpu_baseline(wl, model, mc, seconds_budget=30.0):
                       "oracle of the same training step" % (Bs, wl["B"], wl["T"], len(times))}
 
 
+def pmc_traffic(workload, family):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (FETCH_SIZE doubled as
+    the gfx950 counter reports half of a wide streaming read, plus WRITE_SIZE; made by
+    scripts/pmc_traffic.py from two ``rocprofv3 --pmc`` runs of this benchmark), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") != workload:
+            return None
+        return d["families"][family]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,7 +272,7 @@ def main():
         roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel (+ splitk_reduce): every Dense and "
                           "implicit-GEMM Conv2D launch of a step",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "gemm"),
                 "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep,
                 "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_floor_us": 1e3 * kt.floor_ms,
                 "flops_per_step": gemm_flops_per_step(wl)}
@@ -269,8 +284,9 @@ def main():
                      "launches_per_step": a_calls // nrep}
         c_ms, _ = kt.total_ms(CTC_ENTRIES)
         cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
-        ctc_roof = {"kernel": "ctc_prep + ctc_lattice + ctc_grad", "bound": "hbm", "achieved": cb,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS, "traffic": None,
+        ctc_roof = {"kernel": "ctc_fwd_kernel (row logsumexp + lattice) + ctc_finish + ctc_grad", "bound": "hbm",
+                    "achieved": cb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(args.workload, "ctc"),
                     "ms_per_step": c_ms / nrep, "bytes_per_step": ctc_bytes(wl)}
 
     if rank == 0:
