@@ -54,6 +54,7 @@ _SIGNATURES = {
                                          _P, _P, _P, _P, _P, c_int64, _S]),
     "athena_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "athena_add_layernorm_bwd_slabs": (c_int, [c_int, c_int]),
+    "athena_prepare_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _S]),
     "athena_ln_fold_batched": (c_int, [_P, c_int, c_int, _S]),
     "athena_mha_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_float, _P, c_int, _P, _S]),

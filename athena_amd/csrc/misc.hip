@@ -394,3 +394,41 @@ extern "C" int athena_axpby(float a, const void* x, float b, void* y, long n, in
     ATHENA_CHECK_LAUNCH("athena_axpby");
     return ATHENA_OK;
 }
+
+// ---------------------------------------------------------------- labels and key masks of a step
+// one workgroup per utterance
+__global__ __launch_bounds__(256) void prepare_labels_kernel(const int32_t* __restrict__ labels,
+                                                             const int32_t* __restrict__ label_len,
+                                                             const int32_t* __restrict__ input_len, int U, int Tp,
+                                                             int sos, int eos, int32_t* __restrict__ y0,
+                                                             int32_t* __restrict__ tgt, uint8_t* __restrict__ y_mask,
+                                                             int32_t* __restrict__ logit_len,
+                                                             uint8_t* __restrict__ x_mask) {
+    const int b = blockIdx.x;
+    const int L = U + 1;
+    const int len = label_len[b];
+    const int n = input_len[b];
+    const int tl = (((n + 1) >> 1) + 1) >> 1;        // ceil(ceil(n / 2) / 2)
+    if (threadIdx.x == 0) logit_len[b] = tl;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int yv = i == 0 ? sos : labels[(long)b * U + i - 1];
+        y0[(long)b * L + i] = yv;
+        y_mask[(long)b * L + i] = yv == 0 ? 1 : 0;
+        int tv = i < U ? labels[(long)b * U + i] : 0;
+        if (i == len) tv += eos;
+        tgt[(long)b * L + i] = tv;
+    }
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) x_mask[(long)b * Tp + t] = t >= tl ? 1 : 0;
+}
+
+extern "C" int athena_prepare_labels(const int32_t* labels, const int32_t* label_len, const int32_t* input_len, int B,
+                                     int U, int Tp, int sos, int eos, int32_t* y0, int32_t* tgt, uint8_t* y_mask,
+                                     int32_t* logit_len, uint8_t* x_mask, athena_stream_t stream) {
+    ATHENA_REQUIRE(labels && label_len && input_len && y0 && tgt && y_mask && logit_len && x_mask, ATHENA_E_SHAPE,
+                   "athena_prepare_labels: null operand");
+    ATHENA_REQUIRE(B > 0 && U > 0 && Tp > 0, ATHENA_E_SHAPE, "athena_prepare_labels: bad shape B=%d U=%d T'=%d", B, U, Tp);
+    hipLaunchKernelGGL(prepare_labels_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, labels, label_len, input_len, U,
+                       Tp, sos, eos, y0, tgt, y_mask, logit_len, x_mask);
+    ATHENA_CHECK_LAUNCH("athena_prepare_labels");
+    return ATHENA_OK;
+}

@@ -12,7 +12,8 @@ from ..loss import Seq2SeqSparseCategoricalCrossentropy
 from ..metrics import Seq2SeqSparseCategoricalAccuracy
 from ..runtime import ParamStore, uniform
 from ..utils.hparam import register_and_parse_hparams
-from ..utils.misc import create_multihead_mask, insert_sos_in_labels
+from ..layers.attention import AttnMask
+from ..utils.misc import StepLabels, create_multihead_mask, insert_sos_in_labels
 from .base import BaseModel, to_device_samples
 
 _PRECISIONS = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
@@ -124,13 +125,19 @@ class SpeechTransformer(BaseModel):
     def call(self, samples, training=None):
         self.store.refresh_shadows()
         x0 = samples["input"]
-        y0 = insert_sos_in_labels(samples["output"], self.sos)
         x = self.x_net(x0, training=training)
+        # sos-prefixed labels, eos-terminated targets (kept for the loss), frame counts and both key
+        # masks from one kernel; the reference's separate steps are the fallback for other batch forms
+        prep = StepLabels.build(samples, x.shape[1], self.sos, self.eos)
+        y0 = prep.y0 if prep is not None else insert_sos_in_labels(samples["output"], self.sos)
         y = self.y_net(y0, training=training)
         if self.store.collect_cuts:
             self.store.cuts = [("y_net", y)]
-        input_length = self.compute_logit_length(samples)
-        input_mask, output_mask = create_multihead_mask(x, input_length, y0)
+        if prep is not None:
+            input_mask, output_mask = AttnMask(prep.x_mask, False), AttnMask(prep.y_mask, True)
+        else:
+            input_length = self.compute_logit_length(samples)
+            input_mask, output_mask = create_multihead_mask(x, input_length, y0)
         y, encoder_output = self.transformer(x, y, input_mask, output_mask, input_mask, training=training,
                                              return_encoder_output=True)
         if self.store.collect_cuts:
@@ -148,6 +155,9 @@ class SpeechTransformer(BaseModel):
     def compute_logit_length(self, samples):
         """ceil(ceil(len/2)/2) (speech_transformer.py:156-162)."""
         src = samples["input_length"]
+        prepared = StepLabels.logit_length_for(src)
+        if prepared is not None:
+            return prepared
         hit = getattr(self, "_logit_length_cache", None)
         if hit is not None and hit[0] is src and hit[1] == src._version:
             return hit[2]        # asked for again by the loss with the same batch

@@ -495,6 +495,25 @@ def group_sum(x, ngroups, group, scale, out):
     _lib.check(lib.athena_group_sum(_ptr(x), ngroups, group, scale, _ptr(out), _stream()), "athena_group_sum")
 
 
+def prepare_labels(labels, label_len, input_len, Tp, sos, eos):
+    """(y0, tgt, y_mask, logit_len, x_mask) of a batch in one launch; see ``athena_prepare_labels``."""
+    lib = _lib.load()
+    B, U = labels.shape
+    for t_ in (labels, label_len, input_len):
+        if t_.dtype != torch.int32 or not t_.is_contiguous():
+            raise RuntimeError("athena_amd.prepare_labels: labels and lengths must be contiguous int32")
+    dev = labels.device
+    y0 = torch.empty((B, U + 1), dtype=torch.int32, device=dev)
+    tgt = torch.empty((B, U + 1), dtype=torch.int32, device=dev)
+    y_mask = torch.empty((B, U + 1), dtype=torch.uint8, device=dev)
+    logit_len = torch.empty(B, dtype=torch.int32, device=dev)
+    x_mask = torch.empty((B, Tp), dtype=torch.uint8, device=dev)
+    _lib.check(lib.athena_prepare_labels(_ptr(labels), _ptr(label_len), _ptr(input_len), B, U, Tp, sos, eos, _ptr(y0),
+                                         _ptr(tgt), _ptr(y_mask), _ptr(logit_len), _ptr(x_mask), _stream()),
+               "athena_prepare_labels")
+    return y0, tgt, y_mask, logit_len, x_mask
+
+
 def argmax_rows(logits, ldl, rows, V, out):
     lib = _lib.load()
     if out.dtype != torch.int32 or out.numel() < rows:

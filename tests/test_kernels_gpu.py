@@ -674,3 +674,30 @@ def test_refresh_shadows(ops):
         assert torch.equal(s[:, :c], w.to(torch.bfloat16))
         assert torch.equal(s_t[:, :r], w.t().to(torch.bfloat16))
         assert float(s[:, c:].abs().sum()) == 0.0 and float(s_t[:, r:].abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ label preparation
+def test_prepare_labels_matches_reference_helpers(ops):
+    """One-launch label / mask preparation against the step-by-step helpers that restate
+    athena/utils/misc.py:32-90 and speech_transformer.py:156-162."""
+    from athena_amd.utils import misc
+    g = torch.Generator().manual_seed(5)
+    B, U, V, T = 7, 9, 50, 61
+    labels = torch.randint(1, V - 1, (B, U), generator=g, dtype=torch.int32)
+    lens = torch.tensor([9, 0, 3, 9, 1, 5, 8], dtype=torch.int32)
+    for b in range(B):
+        labels[b, lens[b]:] = 0
+    labels[2, 1] = 0                                  # label id 0 inside a sequence
+    in_len = torch.tensor([61 * 4, 1, 2, 3, 4, 5, 243], dtype=torch.int32)
+    Tp = 61
+    misc.StepLabels.last = None
+    y0 = misc.insert_sos_in_labels(labels, V - 1)
+    tgt = misc.insert_eos_in_labels(labels, V - 1, lens)
+    tl = (((in_len + 1) // 2) + 1) // 2
+    xm = (torch.arange(Tp)[None, :] >= tl[:, None]).to(torch.uint8)
+    got = ops.prepare_labels(labels.to(dev()), lens.to(dev()), in_len.to(dev()), Tp, V - 1, V - 1)
+    assert torch.equal(got[0].cpu(), y0)
+    assert torch.equal(got[1].cpu(), tgt)
+    assert torch.equal(got[2].cpu(), (y0 == 0).to(torch.uint8))
+    assert torch.equal(got[3].cpu(), tl)
+    assert torch.equal(got[4].cpu(), xm)
