@@ -33,3 +33,22 @@ for M, N, K in [(1088, 256, 256), (8000, 256, 64), (8000, 256, 256), (8000, 256,
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     t = chain(lambda: ops.gemm(a, b, c, M, N, K, trans_b=True))
     print("gemm M=%5d N=%5d K=%5d      %.2f us  %.0f TFLOP/s" % (M, N, K, t, 2.0 * M * N * K / t / 1e6))
+
+# does a kernel cost more when its neighbours in the graph are other kernels (cold instruction cache)?
+M, N, K = 1088, 256, 256
+a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+b = torch.randn(N, K, device=dev).to(torch.bfloat16)
+bn = torch.randn(K, N, device=dev).to(torch.bfloat16)
+c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+gamma = torch.ones(N, device=dev)
+beta = torch.zeros(N, device=dev)
+rng = torch.zeros(2, dtype=torch.int64, device=dev)
+f_nt = lambda: ops.gemm(a, b, c, M, N, K, trans_b=True)
+f_nn = lambda: ops.gemm(a, bn, c, M, N, K, trans_b=False)
+f_ln = lambda: ops.add_layernorm_fwd(c, None, gamma, beta, 1e-8, 0.0, rng, 0)
+t_nt, t_nn, t_ln = chain(f_nt), chain(f_nn), chain(f_ln)
+def mix():
+    f_nt(); f_ln(); f_nn(); f_ln()
+t_mix = chain(mix, n=100) / 4
+print("alone: gemm NT %.2f us, gemm NN %.2f us, layernorm %.2f us -> mean of the mix would be %.2f us; measured in a mixed chain %.2f us"
+      % (t_nt, t_nn, t_ln, (t_nt + t_nn + 2 * t_ln) / 4, t_mix))
