@@ -8,6 +8,7 @@ from .models.base import BaseModel
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
 from .solver import BaseSolver, HorovodSolver
+from .utils.checkpoint import Checkpoint
 from .utils.hparam import HParams, register_and_parse_hparams
 from .utils.learning_rate import ExponentialDecayAdam, WarmUpAdam, WarmUpLearningSchedule
 from .utils.metric_check import MetricChecker, set_default_summary_writer
@@ -20,4 +21,5 @@ __all__ = [
     "HorovodSolver", "HParams", "register_and_parse_hparams", "ExponentialDecayAdam", "WarmUpAdam",
     "WarmUpLearningSchedule", "MetricChecker", "set_default_summary_writer", "create_multihead_mask",
     "generate_square_subsequent_mask", "insert_eos_in_labels", "insert_sos_in_labels", "validate_seqs",
+    "Checkpoint",
 ]

@@ -214,3 +214,78 @@ def test_product_path_fails_loudly_without_the_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libathena_hip.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.load()
+
+
+# ------------------------------------------------------------------------------------------ checkpoint manager
+class _CkStore:
+    """The part of ParamStore the checkpoint manager touches, on the CPU."""
+
+    def __init__(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.n_train = 96
+        self.params = torch.randn(128, generator=g)          # tail: non-trainable statistics
+        self.shadows_dirty = False
+
+    def state_dict(self):
+        return {"a.kernel": self.params[:64].clone().view(8, 8), "a.bias": self.params[64:96].clone(),
+                "bn.moving_mean": self.params[96:].clone()}
+
+    def load_state_dict(self, state):
+        self.params[:64] = state["a.kernel"].reshape(-1)
+        self.params[64:96] = state["a.bias"]
+        self.params[96:] = state["bn.moving_mean"]
+        self.shadows_dirty = True
+
+
+class _CkOpt:
+    def __init__(self):
+        self.step = torch.zeros(1, dtype=torch.int64)
+
+    def state_dict(self):
+        return {"iterations": self.step.clone()}
+
+    def load_state_dict(self, state):
+        self.step.copy_(state["iterations"])
+
+
+class _CkModel:
+    class metric:
+        name = "Accuracy"
+
+    def __init__(self, seed):
+        self.store = _CkStore(seed)
+
+
+def test_checkpoint_files_best_loss_nbest_and_average(tmp_path):
+    """Bookkeeping of athena/utils/checkpoint.py:45-122: ckpt-N snapshots, the ``checkpoint`` /
+    ``best_loss`` / ``n_best`` files in the reference's format, restore on construction, restore
+    from best, n-best averaging of the trainable variables only."""
+    from athena_amd import Checkpoint
+    d = str(tmp_path / "ck")
+    model, opt = _CkModel(1), _CkOpt()
+    ck = Checkpoint(checkpoint_directory=d, model=model, optimizer=opt)
+    assert ck.save_counter == 0
+    snaps = []
+    for i, (loss, acc) in enumerate([(3.0, 0.5), (2.0, 0.7), (2.5, 0.9)]):
+        model.store.params.add_(1.0)
+        opt.step += 10
+        snaps.append(model.store.params.clone())
+        ck(loss, {"Accuracy": acc})
+    assert sorted(os.listdir(d)) == ["best_loss", "checkpoint", "ckpt-1", "ckpt-2", "ckpt-3", "n_best"]
+    assert open(os.path.join(d, "checkpoint")).read() == 'model_checkpoint_path: "ckpt-3"'
+    assert open(os.path.join(d, "best_loss")).read() == 'model_checkpoint_path: "ckpt-2"'
+    assert open(os.path.join(d, "n_best")).read() == "ckpt-1\t0.5\nckpt-2\t0.7\nckpt-3\t0.9\n"
+    # a new manager on the same directory resumes from the latest snapshot
+    model2, opt2 = _CkModel(2), _CkOpt()
+    ck2 = Checkpoint(checkpoint_directory=d, model=model2, optimizer=opt2)
+    assert ck2.save_counter == 3 and int(opt2.step) == 30
+    assert torch.equal(model2.store.params, snaps[2])
+    assert ck2.n_best_model == {"ckpt-1": 0.5, "ckpt-2": 0.7, "ckpt-3": 0.9}
+    ck2.restore_from_best()
+    assert torch.equal(model2.store.params, snaps[1])
+    # average of the two snapshots with the highest metric; the statistics tail follows the last one restored
+    ck2.compute_nbest_avg(2)
+    want = (snaps[2][:96] + snaps[1][:96]) / 2
+    assert torch.allclose(model2.store.params[:96], want)
+    assert torch.equal(model2.store.params[96:], snaps[1][96:])
+    assert model2.store.shadows_dirty
