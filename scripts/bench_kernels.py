@@ -118,21 +118,22 @@ def bench_attn():
 
 
 def bench_ctc():
-    print("== CTC B=32 T'=250 V=4233 U=32 fp32 ==")
-    B, T, V, U = 32, 250, 4233, 32
-    ldl = ops.roundup(V, 8)
-    logits = torch.randn(B, T, ldl, device=dev)
-    labels = torch.randint(1, V - 1, (B, U), device=dev, dtype=torch.int32)
-    ll = torch.full((B,), U, dtype=torch.int32, device=dev)
-    tl = torch.full((B,), T, dtype=torch.int32, device=dev)
-    ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev)
-    per = torch.empty(B, device=dev)
-    grad = torch.empty_like(logits)
-    t1 = timeit(lambda: ops.ctc_loss_fwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, per, ws))
-    t2 = timeit(lambda: ops.ctc_loss_bwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, None, 1.0 / B, grad, ws))
-    by = B * T * V * 4
-    print("fwd %8.1f us (%6.0f GB/s read)   bwd %8.1f us (%6.0f GB/s r+w)   total %6.0f GB/s of %d MB" %
-          (t1 * 1e6, by / t1 / 1e9, t2 * 1e6, 2 * by / t2 / 1e9, 3 * by / (t1 + t2) / 1e9, 3 * by >> 20))
+    # the benchmark configuration, the LibriSpeech-long and the CTC-heavy configurations
+    for B, T, V, U in [(32, 250, 4233, 32), (8, 750, 5001, 150), (64, 250, 8001, 200)]:
+        print("== CTC B=%d T'=%d V=%d U=%d fp32 ==" % (B, T, V, U))
+        ldl = ops.roundup(V, 8)
+        logits = torch.randn(B, T, ldl, device=dev)
+        labels = torch.randint(1, V - 1, (B, U), device=dev, dtype=torch.int32)
+        ll = torch.full((B,), U, dtype=torch.int32, device=dev)
+        tl = torch.full((B,), T, dtype=torch.int32, device=dev)
+        ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev)
+        per = torch.empty(B, device=dev)
+        grad = torch.empty_like(logits)
+        t1 = timeit(lambda: ops.ctc_loss_fwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, per, ws))
+        t2 = timeit(lambda: ops.ctc_loss_bwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, None, 1.0 / B, grad, ws))
+        by = B * T * V * 4
+        print("fwd %8.1f us (%6.0f GB/s read)   bwd %8.1f us (%6.0f GB/s r+w)   total %6.0f GB/s of %d MB" %
+              (t1 * 1e6, by / t1 / 1e9, t2 * 1e6, 2 * by / t2 / 1e9, 3 * by / (t1 + t2) / 1e9, 3 * by >> 20))
 
 
 if __name__ == "__main__":
