@@ -781,13 +781,24 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
     const int t_begin = zsplit * per_split;
     const int t_end = min(ntiles, t_begin + per_split);
 
+    // fp32 running sums are emptied into fp64 totals every GV_FLUSH k-tiles: the exact-arithmetic
+    // path also serves contractions over 10^5 rows (weight gradients), where one long fp32 chain
+    // would lose four digits against the fp64 oracle
+    constexpr int GV_FLUSH = 8;
     float acc[4][4];
+    double tot[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) { acc[i][j] = 0.f; tot[i][j] = 0.0; }
 
     for (int t = t_begin; t < t_end; ++t) {
+        if (((t - t_begin) % GV_FLUSH) == GV_FLUSH - 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
+        }
         const int seg = t / tiles_per_seg;
         const int k0 = (t - seg * tiles_per_seg) * GV_BK;
         // 64x16 elements per operand, 4 per thread
@@ -837,6 +848,10 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float)(tot[i][j] + (double)acc[i][j]);
     uint64_t key = 0;
     if (p.epi.drop_thresh) key = rng_key(p.epi.rng_state, p.epi.rng_site);
 #pragma unroll
