@@ -369,7 +369,13 @@ class DenseFn(torch.autograd.Function):
         dense, x2 = ctx.dense, ctx.x2
         B, T, K, N, Np = ctx.shape
         M = B * T
-        if Np != N and dy.stride() == (T * Np, Np, 1) and dy.storage_offset() % 4 == 0 and \
+        g16 = ops.take_bf16_grad(dy)
+        if g16 is not None:
+            # the loss wrote its gradient in bf16 into a padded buffer (padding columns zeroed)
+            if g16.dtype != x2.dtype or g16.numel() != M * Np:
+                raise RuntimeError("DenseFn: bf16 gradient buffer does not match the projection")
+            dy = g16.view(M, Np)
+        elif Np != N and dy.stride() == (T * Np, Np, 1) and dy.storage_offset() % 4 == 0 and \
                 dy.untyped_storage().nbytes() >= (dy.storage_offset() + M * Np) * dy.element_size():
             # a view of a padded buffer (what the loss kernels return): take the buffer itself
             dy = dy.as_strided((M, Np), (Np, 1))

@@ -25,8 +25,9 @@ def _as_padded_rows(logits):
 
 class _CTCLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, labels, label_len, logit_len, blank):
+    def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False):
         B, T, V = logits.shape
+        ctx.bf16_grad = bf16_grad
         U = labels.shape[1]
         src, ldl = _as_padded_rows(logits)
         labels = labels.to(torch.int32).contiguous()
@@ -50,9 +51,12 @@ class _CTCLossFn(torch.autograd.Function):
         src, ldl, labels, label_len, logit_len, ws = ctx.saved
         B, T, V, U, blank = ctx.dims
         gs = gout.to(torch.float32).reshape(1).contiguous()
-        grad = torch.empty((B, T, ldl), dtype=torch.float32, device=src.device)
+        gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
+        grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
         ops.ctc_loss_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, gs, 1.0 / B, grad, ws)
-        return grad[..., :V], None, None, None, None
+        if ctx.bf16_grad:
+            return ops.bf16_grad_standin((B, T, V), grad), None, None, None, None, None
+        return grad[..., :V], None, None, None, None, None
 
 
 class CTCLoss:
@@ -71,7 +75,8 @@ class CTCLoss:
         assert logit_length is not None
         V = logits.shape[-1]
         blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
-        loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank)
+        loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank,
+                                      bool(getattr(logits, "_athena_accepts_bf16_grad", False)))
         # CTCAccuracy on the same logits and lengths picks this up instead of a second pass over them
         logits._athena_ctc_argmax = (best, logits._version, logit_length)
         return loss
@@ -79,8 +84,9 @@ class CTCLoss:
 
 class _CELossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets, ls, mode):
+    def forward(ctx, logits, targets, ls, mode, bf16_grad=False):
         B, L, V = logits.shape
+        ctx.bf16_grad = bf16_grad
         src, ldl = _as_padded_rows(logits)
         targets = targets.to(torch.int32).contiguous()
         rows = B * L
@@ -112,9 +118,12 @@ class _CELossFn(torch.autograd.Function):
         if count is not None:
             gs = gs / count
         gs = gs.contiguous()
-        grad = torch.empty((B, L, ldl), dtype=torch.float32, device=src.device)
+        gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
+        grad = torch.empty((B, L, ldl), dtype=gdt, device=src.device)
         ops.ce_loss_bwd(src, ldl, targets, B * L, V, ls, lse, gs, scale, grad)
-        return grad[..., :V], None, None, None
+        if ctx.bf16_grad:
+            return ops.bf16_grad_standin((B, L, V), grad), None, None, None, None
+        return grad[..., :V], None, None, None, None
 
 
 class Seq2SeqSparseCategoricalCrossentropy:
@@ -134,6 +143,8 @@ class Seq2SeqSparseCategoricalCrossentropy:
     def __call__(self, logits, samples, logit_length=None):
         labels = insert_eos_in_labels(samples["output"], self.eos, samples["output_length"])
         seq_len = labels.shape[1]
-        logits = logits[:, :seq_len, :]
+        if seq_len != logits.shape[1]:
+            logits = logits[:, :seq_len, :]
         mode = "by_token" if self.by_token else ("by_sequence" if self.by_sequence else "mean")
-        return _CELossFn.apply(logits, labels, float(self.smoothing_rate), mode)
+        return _CELossFn.apply(logits, labels, float(self.smoothing_rate), mode,
+                               bool(getattr(logits, "_athena_accepts_bf16_grad", False)))

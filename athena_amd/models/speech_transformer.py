@@ -150,7 +150,10 @@ class SpeechTransformer(BaseModel):
     @staticmethod
     def _project(dense, h):
         """Dense(V): fp32 logits [B, T, V] as a view of rows padded to a multiple of 8 columns."""
-        return DenseFn.apply(h, dense, dense.kernel, dense.bias)
+        y = DenseFn.apply(h, dense, dense.kernel, dense.bias)
+        # the projection's backward pass consumes bf16: the loss kernels may write their gradient so
+        y._athena_accepts_bf16_grad = h.dtype == torch.bfloat16
+        return y
 
     def compute_logit_length(self, samples):
         """ceil(ceil(len/2)/2) (speech_transformer.py:156-162)."""

@@ -551,6 +551,31 @@ def cast(src, dst):
                "athena_cast")
 
 
+# ------------------------------------------------------------------------------------------ bf16 gradient hand-over
+# autograd casts a gradient to the dtype of the tensor it belongs to, so a loss kernel cannot hand a
+# bf16 gradient for fp32 logits back through it.  When the producer of the logits (a vocabulary
+# projection running in bf16) announces that it consumes bf16, the loss writes its gradient in bf16
+# into a padded buffer of its own, registers it here and gives autograd a one-element fp32 stand-in
+# expanded to the logits' shape; the projection's backward pass takes the real buffer back out.
+_BF16_GRADS = {}
+
+
+def bf16_grad_standin(shape, g16):
+    s = torch.empty(1, dtype=torch.float32, device=g16.device)
+    _BF16_GRADS[s.data_ptr()] = g16
+    return s.expand(shape)
+
+
+def take_bf16_grad(dy):
+    """The registered bf16 buffer behind a stand-in (None for an ordinary gradient)."""
+    if dy.dim() == 0 or any(st != 0 for st in dy.stride()):
+        return None
+    g16 = _BF16_GRADS.pop(dy.data_ptr(), None)
+    if g16 is None:
+        raise RuntimeError("athena_amd: a bf16 gradient stand-in reached a consumer without its buffer")
+    return g16
+
+
 def axpby(a, x, b, y):
     if x.numel() != y.numel() or x.dtype != y.dtype:
         raise RuntimeError("athena_amd.axpby: operand mismatch")

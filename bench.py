@@ -67,11 +67,14 @@ def gemm_flops_per_step(wl):
 
 
 def ctc_bytes(wl):
-    """Algorithmic HBM bytes of the CTC loss per step: logits read twice, gradient written once."""
+    """Algorithmic HBM bytes of the CTC loss per step: fp32 logits read twice, the gradient written
+    once (bf16 in the bf16 precision mode: the vocabulary projection's backward pass consumes it
+    as is), the two lattices written and read."""
     T2 = (((wl["T"] + 1) // 2) + 1) // 2
     V = wl["vocab"] + 1
     S = 2 * wl["U"] + 1
-    return wl["B"] * T2 * V * 4 * 3 + wl["B"] * T2 * S * 4 * 2
+    grad_bytes = 2 if wl.get("precision", "bf16") == "bf16" else 4
+    return wl["B"] * T2 * V * (4 * 2 + grad_bytes) + wl["B"] * T2 * S * 4 * 2
 
 
 def attention_flops_per_step(wl):
@@ -220,7 +223,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("ATHENA_FORCE_DP", "0") == "1":
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload], precision=args.precision)
 
     from oracle import model as om      # synthetic batch generator only (inputs, not the measured path)
     model, opt, solver, mc = build(wl, args.precision, seed=1)
