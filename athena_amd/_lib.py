@@ -75,7 +75,8 @@ _SIGNATURES = {
     "athena_bn_finalize": (c_int, [_P, c_long, c_int, c_float, c_float, _P, _P, _P, _S]),
     "athena_bn_relu6_apply": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, _P, _S]),
     "athena_bn_relu6_infer": (c_int, [_P, _P, _P, _P, _P, c_float, c_long, c_int, c_int, _P, _S]),
-    "athena_bn_relu6_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, _P, _P, _P, _S]),
+    "athena_bn_relu6_bwd_scratch_bytes": (c_int64, [c_long, c_int]),
+    "athena_bn_relu6_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, c_int64, _P, _P, _P, _S]),
     "athena_add_pe_dropout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32, _P, _S]),
     "athena_dropout_bwd": (c_int, [_P, c_long, c_int, c_float, c_float, _P, c_uint32, _P, _P, _S]),
     "athena_embed_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32,

@@ -661,18 +661,52 @@ __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict
                                                              const float* __restrict__ beta, float eps, long nchunks,
                                                              int C, T* __restrict__ y) {
     const int cpr = C / 8;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nchunks; e += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % cpr) * 8;
-        float v[8];
-        Vec8<T>::load(x + e * 8, v);
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto coeffs = [&](int c0, float (&sc)[8], float (&sh)[8], float (&be)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c0 + i;
-            float mu, rs;
-            if (INFER) { mu = s0[c]; rs = rsqrtf(s1[c] + eps); }
-            else { mu = s0[c]; rs = s0[C + c]; }
-            v[i] = relu6f((v[i] - mu) * rs * gamma[c] + beta[c]);
+            const float mu = s0[c];
+            const float rs = INFER ? rsqrtf(s1[c] + eps) : s0[C + c];
+            sc[i] = rs * gamma[c];
+            sh[i] = mu;                     // (x - mean) first: no cancellation between large terms
+            be[i] = beta[c];
         }
+    };
+    if (stride % cpr == 0) {
+        // every piece this thread visits holds the same eight channels: their scale and shift stay
+        // in registers and two pieces are in flight per trip
+        float sc[8], sh[8], be[8];
+        coeffs((int)(e0 % cpr) * 8, sc, sh, be);
+        long e = e0;
+        for (; e + stride < nchunks; e += 2 * stride) {
+            float v0[8], v1[8];
+            Vec8<T>::load(x + e * 8, v0);
+            Vec8<T>::load(x + (e + stride) * 8, v1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v0[i] = relu6f(fmaf(v0[i] - sh[i], sc[i], be[i]));
+                v1[i] = relu6f(fmaf(v1[i] - sh[i], sc[i], be[i]));
+            }
+            Vec8<T>::store(y + e * 8, v0);
+            Vec8<T>::store(y + (e + stride) * 8, v1);
+        }
+        if (e < nchunks) {
+            float v0[8];
+            Vec8<T>::load(x + e * 8, v0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v0[i] = relu6f(fmaf(v0[i] - sh[i], sc[i], be[i]));
+            Vec8<T>::store(y + e * 8, v0);
+        }
+        return;
+    }
+    for (long e = e0; e < nchunks; e += stride) {
+        float sc[8], sh[8], be[8], v[8];
+        coeffs((int)(e % cpr) * 8, sc, sh, be);
+        Vec8<T>::load(x + e * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = relu6f(fmaf(v[i] - sh[i], sc[i], be[i]));
         Vec8<T>::store(y + e * 8, v);
     }
 }
@@ -705,14 +739,16 @@ extern "C" int athena_bn_relu6_infer(const void* x, const float* moving_mean, co
     return bn_apply_common(x, moving_mean, moving_var, gamma, beta, eps, rows, C, dtype, y, true, (hipStream_t)stream);
 }
 
-// reduce: scratch[c] += sum dy', scratch[C+c] += sum dy'*xhat over the block's rows
+// reduce: slab[blockIdx.x][c] = sum dy', slab[blockIdx.x][C+c] = sum dy'*xhat over the block's rows
+// (dy' = dy masked by the relu6 gate).  One fp32 slab per workgroup instead of atomics on the 2C
+// totals: a few hundred workgroups adding to the same 2C addresses serialise there.
 #define BN_ROWS_PER_BLOCK 512
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
                                                             const float* __restrict__ mean_rstd, long rows, int C,
-                                                            double* __restrict__ scratch) {
+                                                            float* __restrict__ slabs) {
     __shared__ float red[256][17];
     const int cpr = C / 8;
     const int cpb = min(cpr, 256);
@@ -730,19 +766,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             mu[i] = mean_rstd[c0 + i]; rs[i] = mean_rstd[C + c0 + i];
             ga[i] = gamma[c0 + i]; be[i] = beta[c0 + i];
         }
-        for (long r = r0 + slot; r < r1; r += slots) {
-            const long o = r * C + c0;
-            float dv[8], xv[8];
-            Vec8<T>::load(dy + o, dv);
-            Vec8<T>::load(x + o, xv);
+        auto add_row = [&](const float (&dv)[8], const float (&xv)[8]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float xh = (xv[i] - mu[i]) * rs[i];
                 const float yb = xh * ga[i] + be[i];        // the relu6 gate is recomputed, not read
-                float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
+                const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
                 a1[i] += g;
                 a2[i] += g * xh;
             }
+        };
+        // four rows in flight per thread: a row is one 16-byte piece of each tensor, and the loop
+        // would otherwise wait out a full memory latency per row
+        long r = r0 + slot;
+        for (; r + 3L * slots < r1; r += 4L * slots) {
+            float dv[4][8], xv[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = (r + (long)u * slots) * C + c0;
+                Vec8<T>::load(dy + o, dv[u]);
+                Vec8<T>::load(x + o, xv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add_row(dv[u], xv[u]);
+        }
+        for (; r < r1; r += slots) {
+            const long o = r * C + c0;
+            float dv[8], xv[8];
+            Vec8<T>::load(dy + o, dv);
+            Vec8<T>::load(x + o, xv);
+            add_row(dv, xv);
         }
     }
 #pragma unroll
@@ -750,15 +803,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     __syncthreads();
     if (slot == 0 && chunk < cpr) {
         const int c0 = chunk * 8;
+        float* dst = slabs + (long)blockIdx.x * 2 * C;
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             float s1 = 0.f, s2 = 0.f;
             for (int k = 0; k < slots; ++k) {
                 s1 += red[k * cpb + (threadIdx.x % cpb)][i];
                 s2 += red[k * cpb + (threadIdx.x % cpb)][8 + i];
             }
-            atomicAdd(scratch + c0 + i, (double)s1);
-            atomicAdd(scratch + C + c0 + i, (double)s2);
+            dst[c0 + i] = s1;
+            dst[C + c0 + i] = s2;
         }
+    }
+}
+
+// totals[e] = sum over the slabs, in fp64 and in a fixed order; workgroup = 64 entries x 16 waves
+__global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restrict__ slabs, int nslab, int nent,
+                                                           double* __restrict__ totals) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    double a0 = 0.0, a1 = 0.0;
+    if (e < nent) {
+        int b = w;
+        for (; b + 16 < nslab; b += 32) {
+            a0 += (double)slabs[(long)b * nent + e];
+            a1 += (double)slabs[(long)(b + 16) * nent + e];
+        }
+        if (b < nslab) a0 += (double)slabs[(long)b * nent + e];
+    }
+    red[w][lane] = a0 + a1;
+    __syncthreads();
+    if (w == 0 && e < nent) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        totals[e] = t;
     }
 }
 
@@ -773,22 +853,63 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int cpr = C / 8;
     const long nchunks = rows * cpr;
     const float inv_n = 1.f / (float)rows;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nchunks; e += (long)gridDim.x * blockDim.x) {
-        const int c0 = (int)(e % cpr) * 8;
-        float dv[8], xv[8], o[8];
-        Vec8<T>::load(dy + e * 8, dv);
-        Vec8<T>::load(x + e * 8, xv);
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // dx = k1 * (g - k2 - xhat * k3) with the relu6 gate recomputed from xhat
+    struct Co { float mu[8], rs[8], ga[8], be[8], k1[8], k2[8], k3[8]; };
+    auto coeffs = [&](int c0, Co& k) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = c0 + i;
-            const float mu = mean_rstd[c], rs = mean_rstd[C + c];
-            const float sb = (float)scratch[c], sg = (float)scratch[C + c];
-            const float xh = (xv[i] - mu) * rs;
-            const float yb = xh * gamma[c] + beta[c];
-            const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
-            o[i] = gamma[c] * rs * (g - sb * inv_n - xh * sg * inv_n);
+            k.mu[i] = mean_rstd[c]; k.rs[i] = mean_rstd[C + c];
+            k.ga[i] = gamma[c]; k.be[i] = beta[c];
+            k.k1[i] = k.ga[i] * k.rs[i];
+            k.k2[i] = (float)scratch[c] * inv_n;
+            k.k3[i] = (float)scratch[C + c] * inv_n;
         }
-        Vec8<T>::store(dx + e * 8, o);
+    };
+    auto piece = [&](const Co& k, const float (&dv)[8], const float (&xv)[8], float (&o)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (xv[i] - k.mu[i]) * k.rs[i];
+            const float yb = xh * k.ga[i] + k.be[i];
+            const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
+            o[i] = k.k1[i] * (g - k.k2[i] - xh * k.k3[i]);
+        }
+    };
+    if (stride % cpr == 0) {
+        // the same eight channels on every trip: coefficients in registers, two pieces in flight
+        Co k;
+        coeffs((int)(e0 % cpr) * 8, k);
+        long e = e0;
+        for (; e + stride < nchunks; e += 2 * stride) {
+            float d0[8], x0[8], d1[8], x1[8], o0[8], o1[8];
+            Vec8<T>::load(dy + e * 8, d0);
+            Vec8<T>::load(x + e * 8, x0);
+            Vec8<T>::load(dy + (e + stride) * 8, d1);
+            Vec8<T>::load(x + (e + stride) * 8, x1);
+            piece(k, d0, x0, o0);
+            piece(k, d1, x1, o1);
+            Vec8<T>::store(dx + e * 8, o0);
+            Vec8<T>::store(dx + (e + stride) * 8, o1);
+        }
+        if (e < nchunks) {
+            float d0[8], x0[8], o0[8];
+            Vec8<T>::load(dy + e * 8, d0);
+            Vec8<T>::load(x + e * 8, x0);
+            piece(k, d0, x0, o0);
+            Vec8<T>::store(dx + e * 8, o0);
+        }
+    } else {
+        for (long e = e0; e < nchunks; e += stride) {
+            Co k;
+            coeffs((int)(e % cpr) * 8, k);
+            float dv[8], xv[8], o[8];
+            Vec8<T>::load(dy + e * 8, dv);
+            Vec8<T>::load(x + e * 8, xv);
+            piece(k, dv, xv, o);
+            Vec8<T>::store(dx + e * 8, o);
+        }
     }
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -798,26 +919,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+extern "C" int64_t athena_bn_relu6_bwd_scratch_bytes(long rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    const int64_t nslab = (rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK;
+    return (int64_t)sizeof(double) * 2 * C + (int64_t)sizeof(float) * nslab * 2 * C;     // totals + slabs
+}
+
 extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const float* mean_rstd, const float* gamma,
-                                   const float* beta, long rows, int C, int dtype, double* scratch, void* dx,
-                                   float* dgamma, float* dbeta, athena_stream_t stream) {
+                                   const float* beta, long rows, int C, int dtype, void* scratch,
+                                   int64_t scratch_bytes, void* dx, float* dgamma, float* dbeta,
+                                   athena_stream_t stream) {
     ATHENA_REQUIRE(dy && x && beta && mean_rstd && gamma && scratch && dx && dgamma && dbeta && rows > 0 && C > 0,
                    ATHENA_E_SHAPE, "athena_bn_relu6_bwd: bad arguments");
     ATHENA_REQUIRE(C % 8 == 0, ATHENA_E_ALIGN, "athena_bn_relu6_bwd: C %% 8 required");
+    ATHENA_REQUIRE(scratch_bytes >= athena_bn_relu6_bwd_scratch_bytes(rows, C) && athena_aligned16(scratch),
+                   ATHENA_E_SHAPE, "athena_bn_relu6_bwd: scratch too small (%lld bytes) or misaligned",
+                   (long long)scratch_bytes);
     const int cpr = C / 8;
     hipStream_t s = (hipStream_t)stream;
-    ATHENA_REQUIRE(hipMemsetAsync(scratch, 0, sizeof(double) * 2 * C, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_bn_relu6_bwd: memset failed");
+    double* totals = (double*)scratch;
+    float* slabs = (float*)(totals + 2 * C);
     const int cpb = cpr < 256 ? cpr : 256;
-    dim3 g1((unsigned)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK), (cpr + cpb - 1) / cpb);
+    const int nslab = (int)((rows + BN_ROWS_PER_BLOCK - 1) / BN_ROWS_PER_BLOCK);
+    dim3 g1((unsigned)nslab, (cpr + cpb - 1) / cpb);
     const long nchunks = rows * cpr;
     long blocks = (nchunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    const int nent = 2 * C;
     if (dtype == ATHENA_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean_rstd, rows, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, beta, mean_rstd, gamma, scratch, rows, C, (bf16_t*)dx, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean_rstd, rows, C, slabs);
+        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab, nent, totals);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (bf16_t*)dx, dgamma, dbeta);
     } else if (dtype == ATHENA_F32) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, beta, mean_rstd, rows, C, scratch);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, beta, mean_rstd, gamma, scratch, rows, C, (float*)dx, dgamma, dbeta);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, beta, mean_rstd, rows, C, slabs);
+        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab, nent, totals);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (float*)dx, dgamma, dbeta);
     } else {
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6_bwd: dtype");
     }

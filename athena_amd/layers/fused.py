@@ -483,7 +483,7 @@ class XNetFn(torch.autograd.Function):
         a2m = a2.view(M, F2 * C)
         lin_bwd_w(a2m, dpre, M, net.dense, F2 * C, d)
         da2 = lin_bwd_x(dpre, M, net.dense, d)
-        scratch = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        scratch = ops.bn_relu6_bwd_scratch(max(rows1, rows2), C, dev)
         dc2 = torch.empty_like(c2)
         ops.bn_relu6_bwd(da2, c2, mr2, net.bn2.gamma, net.bn2.beta, rows2, C, scratch, dc2, net.bn2.gamma.grad,
                          net.bn2.beta.grad)

@@ -399,13 +399,19 @@ def bn_relu6_infer(x, moving_mean, moving_var, gamma, beta, eps, rows, C, y):
                                          eps, rows, C, dt(x), _ptr(y), _stream()), "athena_bn_relu6_infer")
 
 
+def bn_relu6_bwd_scratch(rows, C, device):
+    """Scratch tensor (uint8) for ``bn_relu6_bwd``: fp64 totals and the per-workgroup partial sums."""
+    n = int(_lib.load().athena_bn_relu6_bwd_scratch_bytes(rows, C))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
 def bn_relu6_bwd(dy, x, mean_rstd, gamma, beta, rows, C, scratch, dx, dgamma, dbeta):
     lib = _lib.load()
-    if any(t.numel() != rows * C for t in (dy, x, dx)) or scratch.dtype != torch.float64 or \
-            scratch.numel() < 2 * C:
+    if any(t.numel() != rows * C for t in (dy, x, dx)):
         raise RuntimeError("athena_amd.bn_relu6_bwd: bad operands")
     _lib.check(lib.athena_bn_relu6_bwd(_ptr(dy), _ptr(x), _ptr(mean_rstd), _ptr(gamma), _ptr(beta), rows, C, dt(x),
-                                       _ptr(scratch), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()),
+                                       _ptr(scratch), scratch.numel() * scratch.element_size(), _ptr(dx),
+                                       _ptr(dgamma), _ptr(dbeta), _stream()),
                "athena_bn_relu6_bwd")
 
 

@@ -457,7 +457,7 @@ def test_batchnorm_relu6(ops, cd, rows, C):
     y2 = torch.empty_like(y)
     ops.bn_relu6_infer(xd, mr[:C].contiguous(), (1 / mr[C:] ** 2 - 1e-3).contiguous(), gd, bd, 1e-3, rows, C, y2)
     assert_close(y2, y_ref.detach(), TOL[cd] * 2, "bn infer")
-    scratch = torch.empty(2 * C, dtype=torch.float64, device=dev())
+    scratch = ops.bn_relu6_bwd_scratch(rows, C, dev())
     dx = torch.empty_like(xd)
     dg, db = torch.empty(C, device=dev()), torch.empty(C, device=dev())
     ops.bn_relu6_bwd(to_cd(dy, cd), xd, mr, gd, bd, rows, C, scratch, dx, dg, db)
