@@ -111,8 +111,9 @@ __device__ __forceinline__ uint64_t rng_key(const uint64_t* state, uint32_t site
     return k;
 }
 __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
-    // 32-bit integer hash of (key, element index): a handful of VALU ops per element
-    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ (uint32_t)(idx >> 32) * 0x85EBCA77u;
+    // 32-bit integer hash of (key, index): a handful of VALU ops.  The high half of the index enters
+    // through a 24-bit multiply (full rate; 32-bit integer multiplies run at a quarter of it).
+    uint32_t h = (uint32_t)idx * 0x9E3779B1u ^ __umul24((uint32_t)(idx >> 32), 0x5EBCA7u);
     h ^= (uint32_t)key;
     h += (uint32_t)(key >> 32);
     h ^= h >> 16; h *= 0x7FEB352Du;
@@ -120,13 +121,33 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
     h ^= h >> 16;
     return h;
 }
-// returns the multiplier: 0 (dropped) or 1/(1-p)
+// Dropout decisions are drawn two per hash: element idx takes 16 bits of the hash of idx >> 1 and
+// is kept when they reach the 16-bit threshold.  Returns the multiplier: 0 (dropped) or 1/(1-p).
 __device__ __forceinline__ float dropout_mult(uint64_t key, uint64_t idx, uint32_t thresh, float scale) {
-    return rng_u32(key, idx) >= thresh ? scale : 0.f;
+    const uint32_t h = rng_u32(key, idx >> 1);
+    const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+    return u >= thresh ? scale : 0.f;
 }
+// the multipliers of the eight consecutive elements base .. base + 7 (same decisions as
+// dropout_mult); an even base costs four hashes
+__device__ __forceinline__ void dropout_mult8(uint64_t key, uint64_t base, uint32_t thresh, float scale,
+                                              float (&m)[8]) {
+    if (base & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = dropout_mult(key, base + i, thresh, scale);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t h = rng_u32(key, (base >> 1) + i);
+        m[2 * i] = (h & 0xffffu) >= thresh ? scale : 0.f;
+        m[2 * i + 1] = (h >> 16) >= thresh ? scale : 0.f;
+    }
+}
+// 16-bit threshold of a drop probability (0 = dropout off)
 static inline uint32_t dropout_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }

@@ -642,8 +642,10 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
                 }
             }
             if (e.drop_thresh) {
+                float dm[8];
+                dropout_mult8(key, (uint64_t)ci, e.drop_thresh, e.drop_scale, dm);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] *= dropout_mult(key, (uint64_t)(ci + r), e.drop_thresh, e.drop_scale);
+                for (int r = 0; r < 8; ++r) v[r] *= dm[r];
             }
             if (e.colsum) {
 #pragma unroll

@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __r
         Vec8<T>::load(b + base, bv);
         if (thresh) {
             const uint64_t key = rng_key(rng_state, site);
+            float dm[8];
+            dropout_mult8(key, (uint64_t)base, thresh, dscale, dm);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bv[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+            for (int i = 0; i < 8; ++i) bv[i] *= dm[i];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += bv[i];
@@ -306,8 +308,10 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_vec_kernel(const T* __r
                 }
                 if (db) {
                     if (thresh) {
+                        float dm[8];
+                        dropout_mult8(key, (uint64_t)base, thresh, dscale, dm);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) dz[i] *= dropout_mult(key, (uint64_t)(base + i), thresh, dscale);
+                        for (int i = 0; i < 8; ++i) dz[i] *= dm[i];
                     }
                     Vec8<T>::store(db + base, dz);
                 }
