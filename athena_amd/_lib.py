@@ -62,6 +62,7 @@ _SIGNATURES = {
                                c_int, c_float, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _S]),
     "athena_conv3x3s2_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_conv3x3s2_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
+    "athena_conv1_moments_len": (c_int64, []),
     "athena_conv1_bn_stats": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_conv1_bn_relu6_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                           _P, _S]),

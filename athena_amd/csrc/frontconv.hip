@@ -14,9 +14,12 @@
 //             dbeta = sb, dgamma = rstd (sum_t w T - mean sb), and
 //             dw[t][c] = gamma rstd ( T - sb/n S[t] - dgamma/n rstd (sum_u R[t][u] w[u][c] - mean S[t]) ).
 #include "common.h"
+#include <type_traits>
 
 #define FC_K 9                      // taps
 #define FC_NMOM (FC_K + FC_K * FC_K)
+#define FC_NTRI (FC_K + FC_K * (FC_K + 1) / 2)   // tap sums + upper triangle of the tap products: 54 <= 64
+#define FC_MOM_BLOCKS 512                         // workgroups (= slabs) of the moments pass
 
 static inline void fc_same_pad(int n, int* out, int* pad_before) {
     int o = (n + 1) / 2;
@@ -45,8 +48,8 @@ __device__ __forceinline__ void fc_taps(const float* __restrict__ in, int H, int
 
 // ---------------------------------------------------------------- input moments
 __global__ __launch_bounds__(256) void fc_moments_kernel(const float* __restrict__ in, int B, int H, int W, int Ho,
-                                                         int Wo, int ph, int pw, double* __restrict__ mom) {
-    __shared__ double red[4][FC_K + FC_K * (FC_K + 1) / 2];
+                                                         int Wo, int ph, int pw, double* __restrict__ slabs) {
+    __shared__ double red[4][FC_NTRI];
     const long npix = (long)B * Ho * Wo;
     // fp64 throughout: the variance is a difference of these sums
     double s[FC_K], r[FC_K * (FC_K + 1) / 2];
@@ -84,19 +87,42 @@ __global__ __launch_bounds__(256) void fc_moments_kernel(const float* __restrict
         if (lane == 0) red[w][FC_K + t] = v;
     }
     __syncthreads();
-    if (threadIdx.x < FC_K + FC_K * (FC_K + 1) / 2) {
+    if (threadIdx.x < FC_NTRI) {
         const int i = threadIdx.x;
-        const double v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-        if (i < FC_K) {
-            atomicAdd(mom + i, v);
-        } else {
-            // triangular index -> (t, u), t <= u; the matrix is stored full
-            int k = i - FC_K, t = 0;
-            while (k >= FC_K - t) { k -= FC_K - t; ++t; }
-            const int u = t + k;
-            atomicAdd(mom + FC_K + t * FC_K + u, v);
-            if (u != t) atomicAdd(mom + FC_K + u * FC_K + t, v);
+        slabs[(long)blockIdx.x * FC_NTRI + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// sums the per-workgroup slabs in a fixed order and expands the triangle into the full 9x9 matrix:
+// mom[0..9) = tap sums, mom[9 + t*9 + u] = tap products.  One workgroup, 16 waves x 64 entries.
+__global__ __launch_bounds__(1024) void fc_moments_fold_kernel(const double* __restrict__ slabs, int nslab,
+                                                               double* __restrict__ mom) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    if (lane < FC_NTRI) {
+        int b = w;
+        for (; b + 16 < nslab; b += 32) {
+            a0 += slabs[(long)b * FC_NTRI + lane];
+            a1 += slabs[(long)(b + 16) * FC_NTRI + lane];
         }
+        if (b < nslab) a0 += slabs[(long)b * FC_NTRI + lane];
+    }
+    red[w][lane] = a0 + a1;
+    __syncthreads();
+    if (w != 0 || lane >= FC_NTRI) return;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][lane];
+    if (lane < FC_K) {
+        mom[lane] = v;
+    } else {
+        // triangular index -> (t, u), t <= u; the matrix is stored full
+        int k = lane - FC_K, t = 0;
+        while (k >= FC_K - t) { k -= FC_K - t; ++t; }
+        const int u = t + k;
+        mom[FC_K + t * FC_K + u] = v;
+        mom[FC_K + u * FC_K + t] = v;
     }
 }
 
@@ -121,6 +147,8 @@ __global__ void fc_colstats_kernel(const double* __restrict__ mom, const float* 
     stats[C + c] = s2 < 0.0 ? 0.0 : s2;
 }
 
+extern "C" int64_t athena_conv1_moments_len(void) { return FC_NMOM + 6 + (int64_t)FC_MOM_BLOCKS * FC_NTRI; }
+
 extern "C" int athena_conv1_bn_stats(const float* in, const float* w_hwio, int B, int H, int W, int Cout,
                                      double* moments, double* colstats, athena_stream_t stream) {
     ATHENA_REQUIRE(in && w_hwio && moments && colstats && B > 0 && H > 0 && W > 0 && Cout > 0 &&
@@ -130,12 +158,13 @@ extern "C" int athena_conv1_bn_stats(const float* in, const float* w_hwio, int B
     fc_same_pad(H, &Ho, &ph);
     fc_same_pad(W, &Wo, &pw);
     hipStream_t s = (hipStream_t)stream;
-    ATHENA_REQUIRE(hipMemsetAsync(moments, 0, sizeof(double) * FC_NMOM, s) == hipSuccess, ATHENA_E_LAUNCH,
-                   "athena_conv1_bn_stats: memset failed");
+    // moments[0, 90): the result; behind it the per-workgroup slabs (no atomics, fixed order)
+    double* slabs = moments + FC_NMOM + 6;            // 96 doubles in: keeps the slabs 256-byte aligned with the base
     const long npix = (long)B * Ho * Wo;
     long blocks = (npix + 255) / 256;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(fc_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, Ho, Wo, ph, pw, moments);
+    if (blocks > FC_MOM_BLOCKS) blocks = FC_MOM_BLOCKS;
+    hipLaunchKernelGGL(fc_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, Ho, Wo, ph, pw, slabs);
+    hipLaunchKernelGGL(fc_moments_fold_kernel, dim3(1), dim3(1024), 0, s, (const double*)slabs, (int)blocks, moments);
     hipLaunchKernelGGL(fc_colstats_kernel, dim3((Cout + 127) / 128), dim3(128), 0, s, (const double*)moments, w_hwio,
                        Cout, colstats);
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_stats");
@@ -268,35 +297,44 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
         for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) red[i] = 0.f;
         __syncthreads();
     }
-    const long npix = (long)B * Ho * Wo;
-    for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
+    const int npix = B * Ho * Wo;
+    // one pixel's operands as they come from memory: nine input values and CPT gradient /
+    // activation elements (16-byte pieces)
+    constexpr int NV = sizeof(T) == 2 ? CPT / 8 : CPT / 4;
+    typedef typename std::conditional<sizeof(T) == 2, bf16x8_t, float4>::type Piece;
+    struct Raw { float a[FC_K]; Piece g[NV], y[NV]; };
+    auto fetch = [&](int pix, Raw& r) {
         const int q = pix / Wo, wo = pix - q * Wo;
         const int b = q / Ho, ho = q - b * Ho;
-        float a[FC_K], gv[CPT];
-        fc_taps(in, H, W, b, ho, wo, ph, pw, a);
-        if (sizeof(T) == 2) {
+        fc_taps(in, H, W, b, ho, wo, ph, pw, r.a);
+        const Piece* gp = (const Piece*)(g + (long)pix * C + c0);
 #pragma unroll
-            for (int j = 0; j < CPT; j += 8) {
-                const bf16x8_t h = *(const bf16x8_t*)((const bf16_t*)g + (long)pix * C + c0 + j);
+        for (int j = 0; j < NV; ++j) r.g[j] = gp[j];
+        if (act) {
+            const Piece* yp = (const Piece*)(act + (long)pix * C + c0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gv[j + i] = (float)h[i];
-                if (act) {   // g is the gradient w.r.t. the relu6 output: apply the gate read off the activation
-                    const bf16x8_t y = *(const bf16x8_t*)((const bf16_t*)act + (long)pix * C + c0 + j);
+            for (int j = 0; j < NV; ++j) r.y[j] = yp[j];
+        }
+    };
+    auto consume = [&](const Raw& r) {
+        float gv[CPT];
+        if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) gv[j + i] = ((float)y[i] > 0.f && (float)y[i] < 6.f) ? gv[j + i] : 0.f;
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = (float)r.g[j][i];
+                    // g is the gradient w.r.t. the relu6 output: apply the gate read off the activation
+                    if (act) v = ((float)r.y[j][i] > 0.f && (float)r.y[j][i] < 6.f) ? v : 0.f;
+                    gv[8 * j + i] = v;
                 }
-            }
         } else {
 #pragma unroll
-            for (int j = 0; j < CPT; j += 4) {
-                const float4 h = *(const float4*)((const float*)g + (long)pix * C + c0 + j);
-                gv[j] = h.x; gv[j + 1] = h.y; gv[j + 2] = h.z; gv[j + 3] = h.w;
-                if (act) {
-                    const float4 y4 = *(const float4*)((const float*)act + (long)pix * C + c0 + j);
-                    const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+            for (int j = 0; j < NV; ++j) {
+                const float h[4] = {r.g[j].x, r.g[j].y, r.g[j].z, r.g[j].w};
+                const float y[4] = {r.y[j].x, r.y[j].y, r.y[j].z, r.y[j].w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gv[j + i] = (y[i] > 0.f && y[i] < 6.f) ? gv[j + i] : 0.f;
-                }
+                for (int i = 0; i < 4; ++i) gv[4 * j + i] = (!act || (y[i] > 0.f && y[i] < 6.f)) ? h[i] : 0.f;
             }
         }
 #pragma unroll
@@ -304,8 +342,31 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
             const f32x2_t g2 = (f32x2_t){gv[2 * i], gv[2 * i + 1]};
 #pragma unroll
             for (int t = 0; t < FC_K; ++t)
-                acc[t][i] = __builtin_elementwise_fma((f32x2_t){a[t], a[t]}, g2, acc[t][i]);
+                acc[t][i] = __builtin_elementwise_fma((f32x2_t){r.a[t], r.a[t]}, g2, acc[t][i]);
             acc[FC_K][i] += g2;
+        }
+    };
+    // the operands of the next pixel are requested before the current one is accumulated: with
+    // two waves per SIMD (the accumulators take most of the register file) a trip would otherwise
+    // wait out a full memory latency
+    {
+        const int stride = gridDim.x * slots;
+        int pix = blockIdx.x * slots + slot;
+        Raw r0, r1;
+        if (pix < npix) {
+            fetch(pix, r0);
+            while (true) {
+                int nx = pix + stride;
+                if (nx < npix) fetch(nx, r1);
+                consume(r0);
+                if (nx >= npix) break;
+                pix = nx;
+                nx = pix + stride;
+                if (nx < npix) fetch(nx, r0);
+                consume(r1);
+                if (nx >= npix) break;
+                pix = nx;
+            }
         }
     }
     // fold the pixel slots of the workgroup, then store the slab

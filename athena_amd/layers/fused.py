@@ -420,7 +420,7 @@ class XNetFn(torch.autograd.Function):
             # one input channel: conv + BN + relu6 in one pass, statistics in closed form from the
             # input moments; the pre-activation tensor is never stored
             if training:
-                mom1 = torch.empty(ops.CONV1_MOMENTS, dtype=torch.float64, device=dev)
+                mom1 = torch.empty(ops.conv1_moments_len(), dtype=torch.float64, device=dev)
                 mr1 = torch.empty(2 * C, dtype=torch.float32, device=dev)
                 ops.conv1_bn_stats(x0, net.conv1.kernel, B, T, Fd, C, mom1, stats)
                 ops.bn_finalize(stats, rows1, C, BN_EPS, BN_MOMENTUM, mr1, net.bn1.moving_mean,

@@ -320,15 +320,21 @@ def conv3x3s2_wgrad(x, dout, dw, B, H, W, Cin, Cout):
                                           ws.numel(), _stream()), "athena_conv3x3s2_wgrad")
 
 
-CONV1_MOMENTS = 90
+CONV1_MOMENTS = 90          # tap sums and tap products the backward pass reads
+
+
+def conv1_moments_len():
+    """Length (fp64 elements) of the ``moments`` buffer of ``conv1_bn_stats``: the 90 moments
+    followed by the scratch of the reduction."""
+    return int(_lib.load().athena_conv1_moments_len())
 
 
 def conv1_bn_stats(x, w_hwio, B, H, W, Cout, moments, colstats):
     """Input moments and closed-form pre-activation statistics of the one-channel first layer."""
     lib = _lib.load()
     if x.dtype != torch.float32 or w_hwio.dtype != torch.float32 or x.numel() != B * H * W or \
-            w_hwio.numel() != 9 * Cout or moments.dtype != torch.float64 or moments.numel() < CONV1_MOMENTS or \
-            colstats.dtype != torch.float64 or colstats.numel() < 2 * Cout:
+            w_hwio.numel() != 9 * Cout or moments.dtype != torch.float64 or \
+            moments.numel() < conv1_moments_len() or colstats.dtype != torch.float64 or colstats.numel() < 2 * Cout:
         raise RuntimeError("athena_amd.conv1_bn_stats: bad operands")
     _lib.check(lib.athena_conv1_bn_stats(_ptr(x), _ptr(w_hwio), B, H, W, Cout, _ptr(moments), _ptr(colstats),
                                          _stream()), "athena_conv1_bn_stats")

@@ -99,6 +99,29 @@ def bench_conv():
     print("wgrad %8.1f us %7.1f TFLOP/s" % (t * 1e6, fl / t / 1e12))
 
 
+def bench_fc():
+    print("== first layer conv(1->256)+BN+relu6 fused (B=32, 1000x80 -> 500x40x256) bf16 ==")
+    B, H, W, C = 32, 1000, 80, 256
+    Ho, Wo = 500, 40
+    x = torch.randn(B, H, W, device=dev)
+    w = torch.randn(9, C, device=dev) * 0.3
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    mom = torch.zeros(ops.conv1_moments_len(), dtype=torch.float64, device=dev)
+    st = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    mr = torch.empty(2 * C, device=dev)
+    out = torch.empty(B * Ho * Wo, C, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda: ops.conv1_bn_stats(x, w, B, H, W, C, mom, st), reps=5)
+    print("moments + column statistics %8.1f us" % (t * 1e6))
+    ops.bn_finalize(st, B * Ho * Wo, C, 1e-3, 0.99, mr, None, None)
+    t = timeit(lambda: ops.conv1_bn_relu6_fwd(x, w, mr, None, gamma, beta, 1e-3, False, B, H, W, C, out), reps=5)
+    by = out.numel() * 2
+    print("forward  %8.1f us (%5.0f GB/s written)" % (t * 1e6, by / t / 1e9))
+    g = torch.randn_like(out)
+    dw, dg, db = torch.empty(9, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    t = timeit(lambda: ops.conv1_bn_bwd(x, g, w, mom, mr, gamma, B, H, W, C, dw, dg, db, relu6_out=out), reps=5)
+    print("backward %8.1f us (%5.0f GB/s read)" % (t * 1e6, 2 * by / t / 1e9))
+
+
 def bench_attn():
     print("== attention B=32 h=4 T=250 dk=64 bf16 ==")
     B, h, T, dk = 32, 4, 250, 64

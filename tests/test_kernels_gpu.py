@@ -325,7 +325,7 @@ def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
     dy = torch.randn(B, Ho, Wo, C, generator=g, dtype=torch.float64)
     xd, wd = x.float().to(dev()), w.detach().float().to(dev())
     gd, bd = gamma.detach().float().to(dev()), beta.detach().float().to(dev())
-    mom = torch.empty(ops.CONV1_MOMENTS, dtype=torch.float64, device=dev())
+    mom = torch.empty(ops.conv1_moments_len(), dtype=torch.float64, device=dev())
     stats = torch.empty(2 * C, dtype=torch.float64, device=dev())
     ops.conv1_bn_stats(xd, wd, B, H, W, C, mom, stats)
     n = B * Ho * Wo
