@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
                                                      const float* __restrict__ s0, const float* __restrict__ s1,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, int infer, int B, int H, int W, int C, int Ho, int Wo,
-                                                     int ph, int pw, T* __restrict__ out) {
+                                                     int ph, int pw, T* __restrict__ out, int pix_begin) {
     const int cpr = C / 8;                           // 8-channel chunks per pixel; host guarantees 256 % cpr == 0
     const int chunk = threadIdx.x % cpr, slot = threadIdx.x / cpr, slots = 256 / cpr;
     const int c0 = chunk * 8;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
         sh[i] = beta[c0 + i] - mu * sc[i];
     }
     const long npix = (long)B * Ho * Wo;
-    for (int pix = blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
+    for (int pix = pix_begin + blockIdx.x * slots + slot; pix < (int)npix; pix += gridDim.x * slots) {
         const int q = pix / Wo, wo = pix - q * Wo;
         const int b = q / Ho, ho = q - b * Ho;
         float a[FC_K];
@@ -230,6 +230,172 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ i
             *(float4*)op = make_float4(o[0], o[1], o[2], o[3]);
             *(float4*)(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
+    }
+}
+
+// The same layer on the matrix cores for a bf16 result.  Per output pixel the nine products and the
+// BatchNorm shift are one contraction of length 32,
+//     y[c] = sum_t a[t] * (w[t][c] * scale[c]) + shift[c],
+// with every fp32 factor split into two bf16 halves (x = hi + lo) and the three products that
+// matter kept: a_hi w_hi + a_hi w_lo + a_lo w_hi (error ~2^-17 of a term, far below the bf16
+// result).  The 32 contraction slots, in groups of eight as the MFMA lanes hold them:
+//     group 0: a_hi[0..7] x w_hi[0..7]      group 1: a_hi[0..7] x w_lo[0..7]
+//     group 2: a_lo[0..7] x w_hi[0..7]      group 3: a_hi[8] w_hi[8], a_hi[8] w_lo[8], a_lo[8] w_hi[8],
+//                                                    1 x shift_hi, 1 x shift_lo, 0, 0, 0
+// Channels are the MFMA rows, pixels its columns; the rows of two consecutive products are
+// interleaved so that a lane ends up with eight consecutive channels of one pixel (one 16-byte
+// store).  A wave takes 16 pixels x 32 * NPAIR channels per trip; the weight fragments stay in
+// registers.  The vector ALUs only decode the taps and clamp / convert the result.
+__device__ __forceinline__ void fc_split(float x, bf16_t& hi, bf16_t& lo) {
+    hi = (bf16_t)x;
+    lo = (bf16_t)(x - (float)hi);
+}
+
+template <int NPAIR>
+__global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ s0, const float* __restrict__ s1,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int infer, int B,
+                                                          int H, int W, int C, int Ho, int Wo, int ph, int pw,
+                                                          bf16_t* __restrict__ out) {
+    constexpr int CB = 32 * NPAIR;                   // channels per workgroup (blockIdx.y picks the block)
+    constexpr int SROW = CB + 8;                     // padded row of the output staging tile (elements)
+    constexpr int LPR = CB / 8, RPI = 64 / LPR;      // lanes per tile row, rows per store instruction
+    __shared__ float sW[FC_K + 1][CB];               // scaled weights, then the shift
+    __shared__ __attribute__((aligned(16))) bf16_t sO[4][16][SROW];      // one 16-pixel tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, li = lane & 15;
+    const int cb = blockIdx.y * CB;
+    for (int i = tid; i < CB; i += 256) {
+        const int c = cb + i;
+        const float mu = s0[c];
+        const float rs = infer ? rsqrtf(s1[c] + eps) : s0[C + c];
+        const float k = rs * gamma[c];
+#pragma unroll
+        for (int t = 0; t < FC_K; ++t) sW[t][i] = w[t * C + c] * k;
+        sW[FC_K][i] = beta[c] - mu * k;
+    }
+    __syncthreads();
+    // A-operand fragments: row m = lane & 15 of product j of pair P is channel 32 P + 8 (m >> 2) + 4 j + (m & 3)
+    bf16x8_t wf[NPAIR][2];
+#pragma unroll
+    for (int P = 0; P < NPAIR; ++P)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = 32 * P + 8 * (li >> 2) + 4 * j + (li & 3);
+            bf16x8_t f;
+            if (kg < 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    bf16_t hi, lo;
+                    fc_split(sW[e][ch], hi, lo);
+                    f[e] = kg == 1 ? lo : hi;
+                }
+            } else {
+                bf16_t whi, wlo, shi, slo;
+                fc_split(sW[8][ch], whi, wlo);
+                fc_split(sW[FC_K][ch], shi, slo);
+                const bf16_t z = (bf16_t)0.f;
+                f = (bf16x8_t){whi, wlo, whi, shi, slo, z, z, z};
+            }
+            wf[P][j] = f;
+        }
+    // the launch covers whole 64-pixel blocks only (the host sends a ragged tail to the vector
+    // kernel): no store below is predicated, so the wait for the next trip's taps can leave this
+    // trip's stores in flight
+    const int nblk = (B * Ho * Wo) / 64;
+    // the nine input values around a pixel as loaded (address clamped into the image) and the bit
+    // mask of those inside it; the mask is applied when the values are used, a trip later
+    struct Taps { float v[FC_K]; uint32_t ok; };
+    auto fetch = [&](int blk, Taps& t) {
+        const int pix = blk * 64 + wave * 16 + li;
+        const int q = pix / Wo, wo = pix - q * Wo;
+        const int b = q / Ho, ho = q - b * Ho;
+        // addresses first (rows and columns clamped into the image: branch-free and always valid),
+        // then the nine loads back to back
+        uint32_t okm = 0;
+        int idx[FC_K];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = 2 * ho - ph + kh;
+            const int hc = min(max(h, 0), H - 1);
+            const uint32_t hok = (h == hc) ? 1u : 0u;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int x = 2 * wo - pw + kw;
+                const int xc = min(max(x, 0), W - 1);
+                idx[kh * 3 + kw] = (b * H + hc) * W + xc;
+                okm |= (hok & ((x == xc) ? 1u : 0u)) << (kh * 3 + kw);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FC_K; ++i) t.v[i] = in[idx[i]];
+        t.ok = okm;
+    };
+    // B-operand fragment of a pixel from its nine taps
+    auto tap_frag = [&](const Taps& t) {
+        bf16_t hi[FC_K], lo[FC_K];
+#pragma unroll
+        for (int i = 0; i < FC_K; ++i) fc_split(((t.ok >> i) & 1u) ? t.v[i] : 0.f, hi[i], lo[i]);
+        bf16x8_t f;
+        if (kg < 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = kg == 2 ? lo[e] : hi[e];
+        } else {
+            const bf16_t one = (bf16_t)1.f, z = (bf16_t)0.f;
+            f = (bf16x8_t){hi[8], hi[8], lo[8], one, one, z, z, z};
+        }
+        return f;
+    };
+    // one trip: the wave's 16 pixels x CB channels from the taps fetched a trip earlier
+    auto emit = [&](int blk, const Taps& t) {
+        const bf16x8_t pf = tap_frag(t);
+        bf16_t* so = &sO[wave][0][0];
+#pragma unroll
+        for (int P = 0; P < NPAIR; ++P) {
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[P][0], pf, zero, 0, 0, 0);
+            const f32x4_t d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[P][1], pf, zero, 0, 0, 0);
+            bf16x8_t ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // relu6, with a value below 6 kept from rounding up to 6 (the backward pass reads the
+                // relu6 gate off the stored value): 5.96875 is the largest bf16 below 6
+                ov[r] = (bf16_t)(d0[r] >= 6.f ? 6.f : __builtin_amdgcn_fmed3f(d0[r], 0.f, 5.96875f));
+                ov[4 + r] = (bf16_t)(d1[r] >= 6.f ? 6.f : __builtin_amdgcn_fmed3f(d1[r], 0.f, 5.96875f));
+            }
+            *(bf16x8_t*)(so + li * SROW + 32 * P + 8 * kg) = ov;
+        }
+        // the wave's 16 x CB tile goes out in whole rows: a lane's own pieces are 64-byte islands, a
+        // row of the tile is CB * 2 contiguous bytes of the output
+        __builtin_amdgcn_wave_barrier();
+        const int pix0 = blk * 64 + wave * 16;
+#pragma unroll
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int row = it * RPI + lane / LPR, col = (lane % LPR) * 8;
+            const bf16x8_t v = *(const bf16x8_t*)(so + row * SROW + col);
+            *(bf16x8_t*)(out + (long)(pix0 + row) * C + cb + col) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // The taps of the next trip are requested before the current one is worked on, into the other
+    // of two register sets (no copies: a copy would wait for the loads AND for the stores issued
+    // after them).  The fetch is unconditional -- the last trip re-reads its own block -- so the
+    // number of outstanding loads is the same on every path.
+    Taps t0, t1;
+    int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    fetch(blk, t0);
+    while (true) {
+        int nb = blk + gridDim.x;
+        fetch(nb < nblk ? nb : blk, t1);
+        emit(blk, t0);
+        if (nb >= nblk) break;
+        blk = nb;
+        nb = blk + gridDim.x;
+        fetch(nb < nblk ? nb : blk, t0);
+        emit(blk, t1);
+        if (nb >= nblk) break;
+        blk = nb;
     }
 }
 
@@ -264,12 +430,37 @@ extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, c
     long blocks = (npix + slots - 1) / slots;
     if (blocks > 2048) blocks = 2048;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta,
-                           eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out);
-    else
-        hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta,
-                           eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (float*)out);
+    int pix_begin = 0;
+    if (dtype == ATHENA_BF16 && Cout % 32 == 0 && (Cout <= 256 ? (256 % Cout == 0) : (Cout % 256 == 0)) &&
+        npix >= 64) {
+        // matrix-core path for the whole 64-pixel blocks: a workgroup trip is 64 pixels x up to 256 channels
+        const int cbw = Cout < 256 ? Cout : 256;
+        long nb = npix / 64;
+        pix_begin = (int)(nb * 64);
+        if (nb > 1024) nb = 1024;
+        const dim3 grid((unsigned)nb, (unsigned)(Cout / cbw));
+#define FC_MFMA(NP)                                                                                              \
+    hipLaunchKernelGGL(fc_fwd_mfma_kernel<NP>, grid, dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta, eps, infer, B, \
+                       H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out)
+        switch (cbw / 32) {
+            case 1: FC_MFMA(1); break;
+            case 2: FC_MFMA(2); break;
+            case 4: FC_MFMA(4); break;
+            default: FC_MFMA(8); break;
+        }
+#undef FC_MFMA
+    }
+    if (pix_begin < npix) {
+        // everything (fp32), or the ragged tail behind the last whole block
+        blocks = (npix - pix_begin + slots - 1) / slots;
+        if (blocks > 2048) blocks = 2048;
+        if (dtype == ATHENA_BF16)
+            hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
+                               beta, eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out, pix_begin);
+        else
+            hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
+                               beta, eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (float*)out, pix_begin);
+    }
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_relu6_fwd");
     return ATHENA_OK;
 }

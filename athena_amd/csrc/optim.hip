@@ -16,20 +16,33 @@ __device__ __forceinline__ int find_segment(const int64_t* __restrict__ off, int
 }
 
 // sum of squares per tensor: each workgroup reduces one chunk; a chunk may straddle tensors
+#define SUMSQ_CHUNK 16384  // elements per workgroup: 16 four-element loads in flight per thread
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, long n,
                                                          const int64_t* __restrict__ seg_offsets, int nseg,
                                                          float gscale, float* __restrict__ norms) {
     __shared__ float red[32];
-    const long c0 = (long)blockIdx.x * ADAM_CHUNK;
-    const long c1 = min(n, c0 + ADAM_CHUNK);
+    const long c0 = (long)blockIdx.x * SUMSQ_CHUNK;
+    const long c1 = min(n, c0 + SUMSQ_CHUNK);
     int seg = find_segment(seg_offsets, nseg, c0);
     long pos = c0;
     while (pos < c1) {
         const long send = min(c1, (long)seg_offsets[seg + 1]);
         float s = 0.f;
-        for (long i = pos + threadIdx.x; i < send; i += blockDim.x) {
-            float v = g[i] * gscale;
-            s += v * v;
+        if (((pos | send) & 3) == 0 && ((((uintptr_t)g) & 15) == 0)) {
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (long i = pos + 4L * threadIdx.x; i < send; i += 4L * blockDim.x) {
+                const float4 v = *(const float4*)(g + i);
+                s = fmaf(v.x * gscale, v.x * gscale, s);
+                s1 = fmaf(v.y * gscale, v.y * gscale, s1);
+                s2 = fmaf(v.z * gscale, v.z * gscale, s2);
+                s3 = fmaf(v.w * gscale, v.w * gscale, s3);
+            }
+            s = (s + s1) + (s2 + s3);
+        } else {
+            for (long i = pos + threadIdx.x; i < send; i += blockDim.x) {
+                float v = g[i] * gscale;
+                s += v * v;
+            }
         }
         s = block_sum(s, red);
         if (threadIdx.x == 0 && send > pos) atomicAdd(norms + seg, s);
@@ -90,7 +103,8 @@ extern "C" int athena_clip_adam_step(float* params, const float* grads, float* m
     const unsigned blocks = (unsigned)((n + ADAM_CHUNK - 1) / ADAM_CHUNK);
     if (cfg->clip_norm > 0.f) {
         ATHENA_REQUIRE(hipMemsetAsync(norms, 0, sizeof(float) * nseg, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_clip_adam_step: memset failed");
-        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, s, grads, n, seg_offsets, nseg, cfg->grad_scale, norms);
+        const unsigned sblocks = (unsigned)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(sblocks), dim3(256), 0, s, grads, n, seg_offsets, nseg, cfg->grad_scale, norms);
     }
     hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, seg_offsets, nseg, norms, step, *cfg, lr_out);
     hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
