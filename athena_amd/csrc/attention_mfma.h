@@ -92,10 +92,13 @@ __device__ __forceinline__ bf16x8_t att_load8(const bf16_t* base, int row, int n
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// flags of the 64 streamed keys of a block: 0 = attend, 1 = masked (-1e9), 2 = past the end
-__device__ __forceinline__ uint8_t att_key_flag(const uint8_t* __restrict__ key_mask, long b, int Tk, int kj) {
-    if (kj >= Tk) return 2;
-    return (key_mask && key_mask[b * Tk + kj]) ? 1 : 0;
+// additive score bias of a streamed key: 0 = attend, -1e9 = masked (the reference's additive mask),
+// -inf = past the end.  Kept as a float per key so that the score loop is one multiply-add per
+// element with no branches (per-element flag tests compiled into a chain of exec-mask branches
+// that took longer than the matrix products of the block).
+__device__ __forceinline__ float att_key_bias(const uint8_t* __restrict__ key_mask, long b, int Tk, int kj) {
+    if (kj >= Tk) return -INFINITY;
+    return (key_mask && key_mask[b * Tk + kj]) ? -1e9f : 0.f;
 }
 
 // ---------------------------------------------------------------- forward
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
     constexpr int KS = DK / 32, NT = DK / 16;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) uint8_t sM[2][AM_ROWS];
+    __shared__ __attribute__((aligned(16))) float sM[2][AM_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.y / h, hh = blockIdx.y % h;
     const bf16_t* qb = q + (long)b * Tq * ldq + hh * DK;
@@ -125,11 +128,11 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
     float m = -INFINITY, lp = 0.f;
 
     AttStage<DK> stK, stV;
-    uint8_t mflag = 0;
+    float mflag = 0.f;
     const int nblk = (Tk + AM_ROWS - 1) / AM_ROWS;
     stK.load(kb, ldk, 0, Tk, tid);
     stV.load(vb, ldv, 0, Tk, tid);
-    if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, tid);
+    if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, tid);
     stK.store(sK[0], tid);
     stV.store(sV[0], tid);
     if (tid < AM_ROWS) sM[0][tid] = mflag;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
         if (more) {
             stK.load(kb, ldk, j0 + AM_ROWS, Tk, tid);
             stV.load(vb, ldv, j0 + AM_ROWS, Tk, tid);
-            if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, j0 + AM_ROWS + tid);
+            if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, j0 + AM_ROWS + tid);
         }
         // scores, transposed: s[jt][r] = q(qi) . k(j0 + 16 jt + 4 g + r)
         f32x4_t s[4];
@@ -156,14 +159,17 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
         float tmax = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            const uint32_t mk = ((const uint32_t*)sM[cur])[4 * jt + g];
+            const float4 b4 = *(const float4*)&sM[cur][16 * jt + 4 * g];
+            const float kb4[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t f = (mk >> (8 * r)) & 0xffu;
-                const int kj = j0 + 16 * jt + 4 * g + r;
-                float sv = s[jt][r] * scale;
-                if (f == 1u || (causal && kj > qi)) sv += -1e9f;
-                if (f == 2u) sv = -INFINITY;
+                float bias = kb4[r];
+                if (causal) {
+                    // a key that is both padded and ahead of the query gets the additive mask once
+                    const int kj = j0 + 16 * jt + 4 * g + r;
+                    bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
+                }
+                const float sv = s[jt][r] * scale + bias;
                 s[jt][r] = sv;
                 tmax = fmaxf(tmax, sv);
             }
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
     constexpr int KS = DK / 32, NT = DK / 16;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) uint8_t sM[2][AM_ROWS];
+    __shared__ __attribute__((aligned(16))) float sM[2][AM_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
     const int b = blockIdx.y / h, hh = blockIdx.y % h;
     const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
@@ -261,11 +267,11 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     AttStage<DK> stK, stV;
-    uint8_t mflag = 0;
+    float mflag = 0.f;
     const int nblk = (Tk + AM_ROWS - 1) / AM_ROWS;
     stK.load(kb, ldk, 0, Tk, tid);
     stV.load(vb, ldv, 0, Tk, tid);
-    if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, tid);
+    if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, tid);
     stK.store(sK[0], tid);
     stV.store(sV[0], tid);
     if (tid < AM_ROWS) sM[0][tid] = mflag;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
         if (more) {
             stK.load(kb, ldk, j0 + AM_ROWS, Tk, tid);
             stV.load(vb, ldv, j0 + AM_ROWS, Tk, tid);
-            if (tid < AM_ROWS) mflag = att_key_flag(key_mask, b, Tk, j0 + AM_ROWS + tid);
+            if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, j0 + AM_ROWS + tid);
         }
         f32x4_t s[4], dp[4];
 #pragma unroll
@@ -294,14 +300,16 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
         }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            const uint32_t mk = ((const uint32_t*)sM[cur])[4 * jt + g];
+            const float4 b4 = *(const float4*)&sM[cur][16 * jt + 4 * g];
+            const float kb4[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t f = (mk >> (8 * r)) & 0xffu;
-                const int kj = j0 + 16 * jt + 4 * g + r;
-                float sv = s[jt][r] * scale;
-                if (f == 1u || (causal && kj > qi)) sv += -1e9f;
-                if (f == 2u) sv = -INFINITY;
+                float bias = kb4[r];
+                if (causal) {
+                    const int kj = j0 + 16 * jt + 4 * g + r;
+                    bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
+                }
+                const float sv = s[jt][r] * scale + bias;
                 const float p = __expf(sv - lse_i);
                 s[jt][r] = p * (dp[jt][r] - del_i) * scale;     // dS
             }
@@ -418,8 +426,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = i0 + 16 * it + 4 * g + r;
-                float sv = s[it][r] * scale;
-                if (kmask || (causal && kj > qi)) sv += -1e9f;
+                const float sv = s[it][r] * scale + ((kmask || (causal && kj > qi)) ? -1e9f : 0.f);
                 const float p = __expf(sv - lv[r]);
                 s[it][r] = p;
                 dp[it][r] = p * (dp[it][r] - dl[r]) * scale;    // dS
