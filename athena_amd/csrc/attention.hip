@@ -279,11 +279,18 @@ static bool mha_mfma_ok(int dtype, int dk, std::initializer_list<int> lds, std::
     return true;
 }
 
-#define MHA_MFMA_DISPATCH(KERNEL, GRID, ...)                                                     \
-    do {                                                                                         \
-        if (dk == 32) hipLaunchKernelGGL((KERNEL<32>), GRID, dim3(256), 0, s, __VA_ARGS__);      \
-        else if (dk == 64) hipLaunchKernelGGL((KERNEL<64>), GRID, dim3(256), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<128>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+// the causal test of the scores is compiled in only where it is asked for
+#define MHA_MFMA_DISPATCH(KERNEL, GRID, ...)                                                              \
+    do {                                                                                                  \
+        if (causal) {                                                                                     \
+            if (dk == 32) hipLaunchKernelGGL((KERNEL<32, true>), GRID, dim3(256), 0, s, __VA_ARGS__);      \
+            else if (dk == 64) hipLaunchKernelGGL((KERNEL<64, true>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<128, true>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        } else {                                                                                          \
+            if (dk == 32) hipLaunchKernelGGL((KERNEL<32, false>), GRID, dim3(256), 0, s, __VA_ARGS__);     \
+            else if (dk == 64) hipLaunchKernelGGL((KERNEL<64, false>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<128, false>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+        }                                                                                                 \
     } while (0)
 
 #define MHA_DISPATCH(KERNEL, T, ...)                                                                          \

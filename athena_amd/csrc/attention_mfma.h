@@ -102,7 +102,7 @@ __device__ __forceinline__ float att_key_bias(const uint8_t* __restrict__ key_ma
 }
 
 // ---------------------------------------------------------------- forward
-template <int DK>
+template <int DK, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                            const uint8_t* __restrict__ key_mask, int causal, int h,
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float bias = kb4[r];
-                if (causal) {
+                if constexpr (CAUSAL) {
                     // a key that is both padded and ahead of the query gets the additive mask once
                     const int kj = j0 + 16 * jt + 4 * g + r;
                     bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 // dQ: a wave owns 16 queries, keys/values streamed.  delta[b,h,i] = sum_c dout[b,i,h,c] * out[b,i,h,c]
 // is worked out here from the dout fragments the kernel holds anyway (the four lanes of a query
 // cover its DK columns between them) and written out for the dK/dV kernel that follows.
-template <int DK>
+template <int DK, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                               const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                               const uint8_t* __restrict__ key_mask, int causal, int h,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float bias = kb4[r];
-                if (causal) {
+                if constexpr (CAUSAL) {
                     const int kj = j0 + 16 * jt + 4 * g + r;
                     bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
                 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
 }
 
 // dK, dV: a wave owns 16 keys, queries / dout streamed
-template <int DK>
+template <int DK, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                                const uint8_t* __restrict__ key_mask, int causal, int h,
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = i0 + 16 * it + 4 * g + r;
-                const float sv = s[it][r] * scale + ((kmask || (causal && kj > qi)) ? -1e9f : 0.f);
+                const float sv = s[it][r] * scale + ((kmask || (CAUSAL && kj > qi)) ? -1e9f : 0.f);
                 const float p = __expf(sv - lv[r]);
                 s[it][r] = p;
                 dp[it][r] = p * (dp[it][r] - dl[r]) * scale;    // dS
