@@ -12,7 +12,7 @@ void athena_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* athena_last_error(void) { return g_err; }
-extern "C" int athena_abi_version(void) { return 3; }
+extern "C" int athena_abi_version(void) { return 4; }
 
 static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     memset(&e, 0, sizeof(e));
