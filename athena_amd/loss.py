@@ -76,7 +76,7 @@ class CTCLoss:
         V = logits.shape[-1]
         blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
         loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank,
-                                      bool(getattr(logits, "_athena_accepts_bf16_grad", False)))
+                                      ops.bf16_grad_wanted(logits))
         # CTCAccuracy on the same logits and lengths picks this up instead of a second pass over them
         logits._athena_ctc_argmax = (best, logits._version, logit_length)
         return loss
@@ -147,4 +147,4 @@ class Seq2SeqSparseCategoricalCrossentropy:
             logits = logits[:, :seq_len, :]
         mode = "by_token" if self.by_token else ("by_sequence" if self.by_sequence else "mean")
         return _CELossFn.apply(logits, labels, float(self.smoothing_rate), mode,
-                               bool(getattr(logits, "_athena_accepts_bf16_grad", False)))
+                               ops.bf16_grad_wanted(logits))

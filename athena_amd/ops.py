@@ -565,27 +565,49 @@ def cast(src, dst):
 
 # ------------------------------------------------------------------------------------------ bf16 gradient hand-over
 # autograd casts a gradient to the dtype of the tensor it belongs to, so a loss kernel cannot hand a
-# bf16 gradient for fp32 logits back through it.  When the producer of the logits (a vocabulary
-# projection running in bf16) announces that it consumes bf16, the loss writes its gradient in bf16
-# into a padded buffer of its own, registers it here and gives autograd a one-element fp32 stand-in
-# expanded to the logits' shape; the projection's backward pass takes the real buffer back out.
+# bf16 gradient for fp32 logits back through it.  Inside a solver step (``bf16_grad_handover``), when
+# the producer of the logits (a vocabulary projection running in bf16) announces that it consumes
+# bf16, the loss writes its gradient in bf16 into a padded buffer of its own, registers it here and
+# gives autograd a one-element fp32 stand-in expanded to the logits' shape; the projection's
+# backward pass takes the real buffer back out.  The stand-in is NOT the gradient of the logits, so
+# the hand-over is off wherever user code may look at that gradient (plain ``loss.backward()`` /
+# ``torch.autograd.grad`` outside the solver keep the fp32 gradient tensor).
 _BF16_GRADS = {}
+_HANDOVER_DEPTH = 0
+
+
+class bf16_grad_handover:
+    """Context in which the loss functions may hand bf16 gradients to the vocabulary projections."""
+
+    def __enter__(self):
+        global _HANDOVER_DEPTH
+        _HANDOVER_DEPTH += 1
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _HANDOVER_DEPTH
+        _HANDOVER_DEPTH -= 1
+        return False
+
+
+def bf16_grad_wanted(logits):
+    return _HANDOVER_DEPTH > 0 and bool(getattr(logits, "_athena_accepts_bf16_grad", False))
 
 
 def bf16_grad_standin(shape, g16):
     s = torch.empty(1, dtype=torch.float32, device=g16.device)
-    _BF16_GRADS[s.data_ptr()] = g16
+    # the entry keeps the stand-in's storage alive, so no other tensor can have its address
+    # while the entry exists
+    _BF16_GRADS[s.data_ptr()] = (s, g16)
     return s.expand(shape)
 
 
 def take_bf16_grad(dy):
-    """The registered bf16 buffer behind a stand-in (None for an ordinary gradient)."""
+    """The registered bf16 buffer behind a stand-in; None for an ordinary gradient."""
     if dy.dim() == 0 or any(st != 0 for st in dy.stride()):
         return None
-    g16 = _BF16_GRADS.pop(dy.data_ptr(), None)
-    if g16 is None:
-        raise RuntimeError("athena_amd: a bf16 gradient stand-in reached a consumer without its buffer")
-    return g16
+    entry = _BF16_GRADS.pop(dy.data_ptr(), None)
+    return None if entry is None else entry[1]
 
 
 def axpby(a, x, b, y):

@@ -60,10 +60,13 @@ class BaseSolver:
 
     # ------------------------------------------------------------------ one step
     def _forward_backward(self, samples):
-        outputs = self.model(samples, training=True)
-        loss, metrics = self.model.get_loss(outputs, samples, training=True)
-        total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
-        total_loss.backward()
+        # nothing here looks at the gradient of the logits, so the losses may hand it to the
+        # vocabulary projections in bf16
+        with ops.bf16_grad_handover():
+            outputs = self.model(samples, training=True)
+            loss, metrics = self.model.get_loss(outputs, samples, training=True)
+            total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
+            total_loss.backward()
         return loss, metrics
 
     def _reduce_gradients(self):
@@ -239,7 +242,7 @@ class _PipelinedGraphStep:
         g0 = torch.cuda.CUDAGraph()
         store.collect_cuts = True
         try:
-            with torch.cuda.graph(g0, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(g0, capture_error_mode=_CAPTURE_MODE), ops.bf16_grad_handover():
                 outputs = solver.model(self.inputs, training=True)
                 self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
                 total = sum(list(self.loss.values())) if isinstance(self.loss, dict) else self.loss

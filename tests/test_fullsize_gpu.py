@@ -110,7 +110,7 @@ def aishell_oracle():
     loss_ref.backward()
     state = {k: v.detach().float() for k, v in p.items()}
     grads = {k: v.grad for k, v in p.items() if v.grad is not None}
-    out = dict(state=state, grads=grads, samples=samples, loss=float(loss_ref), att=att_ref.detach().float(),
+    out = dict(state=state, grads=grads, samples=samples, loss=float(loss_ref.detach()), att=att_ref.detach().float(),
                ctc=ctc_ref.detach().float(), model=model)
     return out
 

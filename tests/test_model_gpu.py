@@ -252,3 +252,30 @@ def test_dropout_training_runs_and_is_reproducible():
     ops.advance_rng(model.store.rng_state)
     a3, _ = model(ds, training=True)
     assert not torch.equal(a1, a3)
+
+
+def test_bf16_gradient_handover_matches_fp32_gradient_path():
+    """Inside a solver step the losses hand their gradient to the vocabulary projections in bf16
+    through a stand-in tensor; everywhere else the gradient of the logits stays an ordinary fp32
+    tensor.  Both paths must leave the same parameter gradients (the fp32 gradient is rounded to
+    bf16 by the projection's backward pass anyway)."""
+    from athena_amd import ops
+    model, samples, _ = build(SMALL, "bf16")
+    ds = model.prepare_samples(samples)
+    att, ctc = model(ds, training=True)
+    loss, _ = model.get_loss((att, ctc), ds, training=True)
+    # outside the solver: a real gradient of the logits, rows inside the logit length sum to zero
+    g_ctc, = torch.autograd.grad(loss, ctc, retain_graph=True)
+    assert g_ctc.dtype == torch.float32 and all(s != 0 for s in g_ctc.stride())
+    assert torch.isfinite(g_ctc).all() and float(g_ctc.abs().max()) > 0
+    assert float(g_ctc.sum(-1).abs().max()) < 1e-5
+    loss.backward()
+    plain = model.store.grads.clone()
+    model.store.grads.zero_()
+    with ops.bf16_grad_handover():
+        att, ctc = model(ds, training=True)
+        loss2, _ = model.get_loss((att, ctc), ds, training=True)
+        loss2.backward()
+    assert not ops._BF16_GRADS, "a registered bf16 gradient buffer was not consumed"
+    assert float(loss2) == float(loss)
+    assert torch.equal(model.store.grads, plain)
