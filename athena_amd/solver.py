@@ -357,14 +357,20 @@ class HorovodSolver(BaseSolver):
     (solver.py:142-218).  Launch with ``torchrun --nproc-per-node N``; the name is kept so that
     ``from athena import HorovodSolver`` keeps working."""
 
+    # Bucket size of the pipelined exchange (pieces of the backward pass, each piece's gradients
+    # exchanged while the next piece runs): small enough to start early.
     BUCKET_MB = float(os.environ.get("ATHENA_DP_BUCKET_MB", "25"))
+    # Message size of the exchange behind the whole backward pass: nothing overlaps it, so fewer and
+    # larger collectives are better (an xGMI ring is per-link bound and reaches its bandwidth only
+    # on long messages); the AISHELL model's 84 MB go out as one all-reduce.
+    EXCHANGE_MB = float(os.environ.get("ATHENA_DP_EXCHANGE_MB", "256"))
 
     def __init__(self, model, optimizer, sample_signature=None, eval_sample_signature=None, config=None, **kwargs):
         super().__init__(model, optimizer, sample_signature, eval_sample_signature, config, **kwargs)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         st = model.store
-        self._buckets = bucket_ranges(st.seg_offsets.tolist(), st.n_train, int(self.BUCKET_MB * (1 << 20) / 4))
+        self._buckets = bucket_ranges(st.seg_offsets.tolist(), st.n_train, int(self.EXCHANGE_MB * (1 << 20) / 4))
         self._broadcast_done = False
         # ATHENA_FORCE_DP=1 runs the exchange (and the two-graph step) even with one rank: a way to
         # exercise the RCCL path on a single GPU

@@ -45,7 +45,7 @@ def _worker(rank, world, port, bucket_mb, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from athena_amd import HorovodSolver, WarmUpAdam
-    HorovodSolver.BUCKET_MB = bucket_mb
+    HorovodSolver.BUCKET_MB = HorovodSolver.EXCHANGE_MB = bucket_mb
     HorovodSolver.initialize_devices()
     assert dist.is_initialized() and dist.get_backend() == "gloo"
     model = _Model(rank)
