@@ -217,6 +217,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that write banners to file
+    # descriptor 1 (RCCL prints its version block there at initialisation) are sent to stderr, and
+    # the line is written to the saved descriptor and flushed before the process group is torn down
+    # (a buffered line was lost at exit when stdout was a file)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -307,7 +315,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, model, mc)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
