@@ -400,6 +400,12 @@ class HorovodSolver(BaseSolver):
 
     def _exchange_async(self, t):
         """Start the sum of a slice of the flat gradient buffer over the ranks; returns the handle."""
+        if t.is_cuda and dist.get_backend() == "gloo":
+            # rehearsal of the multi-rank step on a box with fewer GPUs than ranks: gloo sums on the host
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
     def _reduce_gradients(self):

@@ -228,10 +228,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    # ATHENA_DIST_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks then share devices; RCCL itself refuses two ranks on one GPU)
+    backend = os.environ.get("ATHENA_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
     if world > 1 or os.environ.get("ATHENA_FORCE_DP", "0") == "1":
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     wl = dict(WORKLOADS[args.workload], precision=args.precision)
+
+    wd = float(os.environ.get("ATHENA_BENCH_WATCHDOG", "0"))
+    if wd > 0:                       # Python stacks of every thread if the run is still going after wd seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=False, file=sys.stderr)
+
+    def log(msg):
+        sys.stderr.write("[bench rank %d/%d] %s\n" % (rank, world, msg))
+        sys.stderr.flush()
 
     from oracle import model as om      # synthetic batch generator only (inputs, not the measured path)
     model, opt, solver, mc = build(wl, args.precision, seed=1)
@@ -249,16 +265,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    log("model built, %d warm-up steps" % args.warmup)
+    for i in range(args.warmup):
         loss, _ = solver.train_step(ds)
+        if world > 1:
+            torch.cuda.synchronize()
+            log("warm-up step %d done" % i)
     barrier()
+    log("timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = solver.train_step(ds)
     barrier()
     dt = time.perf_counter() - t0
+    log("timed region done: %.3f ms per step" % (dt / args.steps * 1e3))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
@@ -268,6 +290,10 @@ def main():
     if rank == 0:
         was = solver.hparams.enable_tf_function
         solver.hparams.enable_tf_function = False
+        # this pass runs on rank 0 alone: the gradient exchange is switched off for it (the other
+        # ranks are not taking steps any more and would never join the collective)
+        was_dp = (solver.world_size, getattr(solver, "_force_exchange", False))
+        solver.world_size, solver._force_exchange = 1, False
         nrep = 3
         solver.train_step(ds)
         with KernelTimer(GEMM_ENTRIES + ATTN_ENTRIES + CTC_ENTRIES) as kt:
@@ -277,6 +303,7 @@ def main():
                 solver.train_step(ds)
                 torch.cuda.synchronize()
         solver.hparams.enable_tf_function = was
+        solver.world_size, solver._force_exchange = was_dp
         g_ms, g_calls = kt.total_ms(GEMM_ENTRIES)
         flops = gemm_flops_per_step(wl) * nrep
         ach = flops / (g_ms * 1e-3) / 1e12
@@ -317,6 +344,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, model, mc)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
+        log("waiting for the other ranks")
+        barrier()          # the other ranks wait here for rank 0's timing pass before the group goes away
         dist.destroy_process_group()
 
 
