@@ -182,7 +182,11 @@ extern "C" int athena_gemm_grouped(const athena_gemm_desc* descs, int count, ath
         const bool bt128 = big && (t128 >= 192 || (all_auto && t128 * min_k8 >= 256));
         const int bt = bt128 ? 128 : 64;
         const long base = bt128 ? t128 : t64;
-        long want = all_auto ? (640 + base - 1) / base : 1;
+        // the same split for every problem of the group, chosen so that all workgroups of the launch
+        // find a place in one round (a little below the 512 places: problems whose tile counts do not
+        // divide evenly add a few)
+        long want = all_auto ? (GM_WG_SLOTS - 32) / base : 1;
+        if (want < 1) want = 1;
         GemmGroup grp;
         ReduceGroup red;
         memset(&grp, 0, sizeof(grp));

@@ -1029,6 +1029,7 @@ static void launch_mfma(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_
 // tiles, so they are used whenever they still fill the chip (~256 CUs, two workgroups each) --
 // on their own, or together with a K split that leaves each workgroup at least 8 k-tiles.
 struct GemmPlan { int bt, split; };
+#define GM_WG_SLOTS 512      // 256 CUs x 2 resident workgroups of the 128x128-tile kernels
 
 static inline GemmPlan gemm_plan(int M, int N, long k_elems, int in_dtype, int zbatch, bool may_split) {
     GemmPlan pl;
@@ -1046,7 +1047,10 @@ static inline GemmPlan gemm_plan(int M, int N, long k_elems, int in_dtype, int z
     }
     const long ktiles = (k_elems + GM_BK - 1) / GM_BK;
     const long t128 = gemm_tiles(M, N, 128) * zbatch;
-    long s128 = may_split ? (512 + t128 - 1) / t128 : 1;
+    // 128x128 tiles run two workgroups per CU: tiles x splits must not exceed those 512 places, or
+    // the few workgroups beyond them run as a second round behind the first (conv2 weight gradient:
+    // 540 workgroups 563 us, 504 workgroups 350 us)
+    long s128 = may_split ? GM_WG_SLOTS / t128 : 1;
     if (s128 > ktiles / 8) s128 = ktiles / 8;
     if (s128 < 1) s128 = 1;
     if (M > 64 && N > 64 && (t128 >= 192 || t128 * s128 >= 256)) {
@@ -1055,7 +1059,7 @@ static inline GemmPlan gemm_plan(int M, int N, long k_elems, int in_dtype, int z
         return pl;
     }
     const long t64 = gemm_tiles(M, N, 64) * zbatch;
-    long s64 = may_split ? 512 / (t64 > 0 ? t64 : 1) : 1;
+    long s64 = may_split ? GM_WG_SLOTS / (t64 > 0 ? t64 : 1) : 1;
     if (s64 > ktiles / 4) s64 = ktiles / 4;
     if (s64 < 1) s64 = 1;
     if (s64 > 256) s64 = 256;
