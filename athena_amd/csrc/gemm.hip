@@ -185,7 +185,8 @@ extern "C" int athena_gemm_grouped(const athena_gemm_desc* descs, int count, ath
         // the same split for every problem of the group, chosen so that all workgroups of the launch
         // find a place in one round (a little below the 512 places: problems whose tile counts do not
         // divide evenly add a few)
-        long want = all_auto ? (GM_WG_SLOTS - 32) / base : 1;
+        // (the 64x64-tile kernel keeps more workgroups resident: its launches aim at 640 of them)
+        long want = !all_auto ? 1 : bt128 ? (GM_WG_SLOTS - 32) / base : (640 + base - 1) / base;
         if (want < 1) want = 1;
         GemmGroup grp;
         ReduceGroup red;
