@@ -1,0 +1,114 @@
+"""A dataset builder of synthetic utterances with the interface the training entry point uses.
+
+It stands where the reference's ``SpeechRecognitionDatasetBuilder``
+(athena/data/datasets/speech_recognition.py:25-206, athena/data/datasets/base.py:29-161) stands:
+``num_class``, ``sample_shape`` / ``sample_type`` / ``sample_signature``, ``hparams`` (text_config,
+words), ``shard``, ``batch_wise_shuffle``, ``compute_cmvn_if_necessary`` and ``as_dataset``, which
+yields the same ``samples`` dicts (``input`` [B, T, F, channels] fp32 zero-padded, ``input_length``,
+``output`` [B, U] int32 zero-padded, ``output_length``).  The utterances are seeded random
+features and labels, sorted by length as the reference does for its first epochs ("sorta").
+CSV / vocabulary / CMVN reading of real corpora is not part of this package.
+"""
+import numpy as np
+import torch
+
+from ..utils.hparam import register_and_parse_hparams
+
+
+class SyntheticSpeechRecognitionDatasetBuilder:
+    default_config = {
+        "num_utterances": 64,
+        "min_frames": 100,
+        "max_frames": 200,
+        "feat_dim": 40,
+        "num_channels": 1,
+        "vocab_size": 30,          # label ids 1 .. vocab_size - 1; 0 is padding / <unk>
+        "min_labels": 3,
+        "max_labels": 8,
+        "seed": 1,
+        "text_config": {"type": "vocab", "model": None},
+        "words": None,
+    }
+
+    def __init__(self, config=None):
+        self.hparams = register_and_parse_hparams(self.default_config, config, cls=self.__class__)
+        p = self.hparams
+        rng = np.random.default_rng(p.seed)
+        self.entries = []
+        for _ in range(p.num_utterances):
+            frames = int(rng.integers(p.min_frames, p.max_frames + 1))
+            # every utterance keeps room for its labels after the two stride-2 convolutions
+            n_lab = int(rng.integers(p.min_labels, min(p.max_labels, max(frames // 8, p.min_labels)) + 1))
+            feat = rng.standard_normal((frames, p.feat_dim, p.num_channels)).astype(np.float32)
+            labels = rng.integers(1, p.vocab_size, size=n_lab).astype(np.int32)
+            self.entries.append((feat, labels))
+        self.entries.sort(key=lambda e: e[0].shape[0])              # "sorta": by duration
+        self.order = list(range(len(self.entries)))
+
+    # ---- what the models read ------------------------------------------------------------------
+    @property
+    def num_class(self):
+        return self.hparams.vocab_size
+
+    @property
+    def sample_type(self):
+        return {"input": torch.float32, "input_length": torch.int32, "output": torch.int32,
+                "output_length": torch.int32}
+
+    @property
+    def sample_shape(self):
+        p = self.hparams
+        return {"input": (None, p.feat_dim, p.num_channels), "input_length": (), "output": (None,),
+                "output_length": ()}
+
+    @property
+    def sample_signature(self):
+        p = self.hparams
+        return ({"input": ((None, None, p.feat_dim, p.num_channels), torch.float32),
+                 "input_length": ((None,), torch.int32), "output": ((None, None), torch.int32),
+                 "output_length": ((None,), torch.int32)},)
+
+    # ---- what the training loop calls (base.py:117-161) ------------------------------------------
+    def __len__(self):
+        return len(self.order)
+
+    def shard(self, num_shards, index):
+        """Keep every ``num_shards``-th utterance starting at ``index`` (base.py:126-138)."""
+        if num_shards > 1:
+            self.order = self.order[index::num_shards]
+        return self
+
+    def batch_wise_shuffle(self, batch_size=64):
+        """Shuffle whole batches, keeping utterances of similar length together (base.py:140-161)."""
+        if len(self.order) <= batch_size:
+            return self
+        rng = np.random.default_rng(self.hparams.seed + len(self.order))
+        nb = len(self.order) // batch_size
+        head, tail = self.order[:nb * batch_size], self.order[nb * batch_size:]
+        batches = [head[i * batch_size:(i + 1) * batch_size] for i in range(nb)]
+        rng.shuffle(batches)
+        self.order = [i for b in batches for i in b] + tail
+        return self
+
+    def compute_cmvn_if_necessary(self, is_necessary=True):
+        """The synthetic features are unit-variance already."""
+        return self
+
+    def as_dataset(self, batch_size=16, num_threads=1):
+        """List of padded batches (``samples`` dicts of CPU tensors)."""
+        out = []
+        for i in range(0, len(self.order), batch_size):
+            chunk = [self.entries[j] for j in self.order[i:i + batch_size]]
+            T = max(f.shape[0] for f, _ in chunk)
+            U = max(l.shape[0] for _, l in chunk)
+            p = self.hparams
+            x = np.zeros((len(chunk), T, p.feat_dim, p.num_channels), np.float32)
+            y = np.zeros((len(chunk), U), np.int32)
+            for k, (f, l) in enumerate(chunk):
+                x[k, :f.shape[0]] = f
+                y[k, :l.shape[0]] = l
+            out.append({"input": torch.from_numpy(x),
+                        "input_length": torch.tensor([f.shape[0] for f, _ in chunk], dtype=torch.int32),
+                        "output": torch.from_numpy(y),
+                        "output_length": torch.tensor([l.shape[0] for _, l in chunk], dtype=torch.int32)})
+        return out

@@ -20,6 +20,8 @@ def _scalar(tag, value, step):
     if _SUMMARY_DIR is None:
         return
     with open(os.path.join(_SUMMARY_DIR, "scalars.tsv"), "a") as f:
+        if hasattr(value, "detach"):
+            value = value.detach()
         f.write("%d\t%s\t%.8g\n" % (step, tag, float(value)))
 
 
@@ -48,7 +50,7 @@ class MetricChecker:
         reports = ""
         reports += "global_steps: %d\t" % (global_steps)
         reports += "learning_rate: %.4e\t" % (learning_rate)
-        reports += "loss: %.4f\t" % (float(total_loss))
+        reports += "loss: %.4f\t" % (float(total_loss.detach() if hasattr(total_loss, "detach") else total_loss))
         if isinstance(loss, dict):
             for name in loss:
                 reports += "%s: %.4f\t" % (name, float(loss[name]))
@@ -73,7 +75,7 @@ class MetricChecker:
         if epoch >= 0:
             _scalar("evaluate_total_loss", total_loss, global_steps)
             reports += "epoch: %d\t" % (epoch)
-        reports += "loss: %.4f\t" % (float(total_loss))
+        reports += "loss: %.4f\t" % (float(total_loss.detach() if hasattr(total_loss, "detach") else total_loss))
         if isinstance(loss, dict):
             for name in loss:
                 reports += "%s: %.4f\t" % (name, float(loss[name]))

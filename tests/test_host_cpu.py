@@ -289,3 +289,59 @@ def test_checkpoint_files_best_loss_nbest_and_average(tmp_path):
     assert torch.allclose(model2.store.params[:96], want)
     assert torch.equal(model2.store.params[96:], snaps[1][96:])
     assert model2.store.shadows_dirty
+
+
+# ------------------------------------------------------------------------------------------ training entry point
+def test_main_config_defaults_and_recipes_parse():
+    """Top-level JSON keys of the training entry point (reference athena/main.py:58-98): defaults,
+    KeyError for unknown keys, and the shipped recipes parse unchanged."""
+    import glob
+    import json
+    from athena_amd import main as amain
+    p = amain.parse_config(None)
+    assert p.batch_size == 32 and p.num_epochs == 20 and p.sorta_epoch == 1 and p.model == "speech_transformer"
+    assert p.optimizer == "warmup_adam" and p.dataset_builder == "speech_recognition_dataset" and p.solver_gpu == [0]
+    with pytest.raises(KeyError):
+        amain.parse_config({"no_such_key": 1})
+    here = os.path.dirname(os.path.abspath(__file__))
+    recipes = sorted(glob.glob(os.path.join(here, "golden", "configs", "*.json")))
+    assert recipes
+    for path in recipes:
+        cfg = json.load(open(path))
+        p = amain.parse_config(cfg)
+        assert p.model == "mtl_transformer_ctc" and p.model in amain.SUPPORTED_MODEL
+        assert p.batch_size == cfg["batch_size"] and p.model_config == cfg["model_config"]
+    with pytest.raises(NotImplementedError):
+        amain.SUPPORTED_DATASET_BUILDER["speech_recognition_dataset"](None)
+
+
+def test_synthetic_dataset_builder_batches_shards_and_shuffles():
+    from athena_amd.data import SyntheticSpeechRecognitionDatasetBuilder as Builder
+    cfg = {"num_utterances": 37, "min_frames": 40, "max_frames": 90, "feat_dim": 8, "vocab_size": 12,
+           "min_labels": 2, "max_labels": 5}
+    b = Builder(cfg)
+    assert b.num_class == 12 and b.sample_shape["input"] == (None, 8, 1) and len(b) == 37
+    batches = b.as_dataset(8)
+    assert len(batches) == 5 and sum(s["input"].shape[0] for s in batches) == 37
+    for s in batches:
+        B, T = s["input"].shape[:2]
+        assert s["input"].shape[2:] == (8, 1) and s["output"].shape[0] == B
+        assert int(s["input_length"].max()) == T and int(s["output_length"].max()) == s["output"].shape[1]
+        for k in range(B):
+            n, u = int(s["input_length"][k]), int(s["output_length"][k])
+            assert float(s["input"][k, n:].abs().sum()) == 0.0 and int(s["output"][k, u:].abs().sum()) == 0
+            assert int(s["output"][k, :u].min()) >= 1 and int(s["output"][k, :u].max()) < 12
+            assert ((n + 1) // 2 + 1) // 2 >= u          # the labels fit the subsampled frames
+    # sorted by duration before the first shuffle
+    lens = [int(x) for s in batches for x in s["input_length"]]
+    assert lens == sorted(lens)
+    # shards are disjoint and cover the set
+    parts = [Builder(cfg).shard(3, r) for r in range(3)]
+    assert sorted(i for p in parts for i in p.order) == list(range(37))
+    # a batch-wise shuffle permutes whole batches and keeps every utterance
+    before = list(b.order)
+    b.batch_wise_shuffle(8)
+    assert sorted(b.order) == sorted(before) and b.order != before
+    assert {tuple(b.order[i:i + 8]) for i in range(0, 32, 8)} == {tuple(before[i:i + 8]) for i in range(0, 32, 8)}
+    with pytest.raises(KeyError):
+        Builder({"unknown": 1})

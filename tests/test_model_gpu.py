@@ -279,3 +279,35 @@ def test_bf16_gradient_handover_matches_fp32_gradient_path():
     assert not ops._BF16_GRADS, "a registered bf16 gradient buffer was not consumed"
     assert float(loss2) == float(loss)
     assert torch.equal(model.store.grads, plain)
+
+
+def test_training_entry_point_epochs_checkpoints_and_resume(tmp_path):
+    """``athena_amd.main.train`` (reference athena/main.py:131-185): two epochs over a synthetic set
+    leave the reference's checkpoint files, and a second call picks up at the saved epoch."""
+    import json
+    from athena_amd import BaseSolver
+    from athena_amd import main as amain
+    ckpt = tmp_path / "ckpts"
+    data = {"num_utterances": 20, "min_frames": 48, "max_frames": 80, "feat_dim": 12, "vocab_size": 10,
+            "min_labels": 2, "max_labels": 4}
+    cfg = {"batch_size": 8, "num_epochs": 2, "sorta_epoch": 1, "ckpt": str(ckpt), "summary_dir": str(tmp_path / "event"),
+           "solver_config": {"clip_norm": 100.0, "log_interval": 1, "enable_tf_function": False},
+           "model": "mtl_transformer_ctc", "model_config": copy.deepcopy(TINY["mc"]),
+           "optimizer": "warmup_adam", "optimizer_config": {"d_model": 32, "warmup_steps": 5, "k": 0.5},
+           "dataset_builder": "synthetic_speech_recognition", "trainset_config": data,
+           "devset_config": dict(data, seed=2, num_utterances=8)}
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    loss, metrics = amain.train(str(path), BaseSolver)
+    assert loss == loss and set(metrics) == {"Accuracy", "CTCAccuracy"}
+    names = sorted(os.listdir(ckpt))
+    assert names == ["best_loss", "checkpoint", "ckpt-1", "ckpt-2", "n_best"], names
+    assert (ckpt / "checkpoint").read_text() == 'model_checkpoint_path: "ckpt-2"'
+    assert len((ckpt / "n_best").read_text().strip().split("\n")) == 2
+    # resume: the checkpoint says two epochs are done; one more is run for num_epochs = 3
+    cfg["num_epochs"] = 3
+    path.write_text(json.dumps(cfg))
+    p, model, optimizer, checkpointer = amain.build_model_from_jsonfile(str(path))
+    assert int(checkpointer.save_counter) == 2 and optimizer.iterations == 6      # 3 batches x 2 epochs
+    amain.train(str(path), BaseSolver)
+    assert "ckpt-3" in os.listdir(ckpt) and "ckpt-4" not in os.listdir(ckpt)
