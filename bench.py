@@ -32,6 +32,14 @@ WORKLOADS = {
     "timit_b16_t500": dict(B=16, T=500, feat=40, vocab=49, U=40, d_model=256, num_filters=256, heads=8, enc=9,
                            dec=3, dff=1024, rate=0.2, opt=dict(d_model=256, warmup_steps=4000, k=1.0),
                            clip_norm=100.0),
+    # LibriSpeech recipe dimensions on long utterances (attention over 750 frames, long CTC lattice)
+    "librispeech_b8_t3000": dict(B=8, T=3000, feat=80, vocab=5000, U=150, d_model=512, num_filters=512, heads=8,
+                                 enc=12, dec=6, dff=2048, rate=0.1,
+                                 opt=dict(d_model=512, warmup_steps=25000, k=1.0), clip_norm=5.0),
+    # AISHELL recipe as shipped (d=512, 8 heads, 40-dim features)
+    "aishell_shipped_b32_t1000": dict(B=32, T=1000, feat=40, vocab=4232, U=32, d_model=512, num_filters=512,
+                                      heads=8, enc=12, dec=6, dff=1280, rate=0.1,
+                                      opt=dict(d_model=512, warmup_steps=25000, k=1.0), clip_norm=100.0),
     "tiny": dict(B=4, T=64, feat=16, vocab=30, U=5, d_model=64, num_filters=32, heads=2, enc=2, dec=1, dff=128,
                  rate=0.1, opt=dict(d_model=64, warmup_steps=10, k=1.0), clip_norm=100.0),
 }
