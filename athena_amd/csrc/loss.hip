@@ -163,6 +163,51 @@ __device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V
     m_out = gm;
 }
 
+// fp32 rows of at most CTC_ROW_REGS * 1024 columns with ld % 4 == 0: the whole row is fetched into
+// registers before anything depends on it (all loads of a thread in flight at once instead of one
+// per trip of an online loop), then maximum, first arg-max and the sum of exponentials relative to
+// the workgroup's maximum are taken from the registers.  Columns V .. ld-1 are padding and masked.
+#define CTC_ROW_REGS 8
+__device__ __forceinline__ void row_max_sum_arg_regs(const float* __restrict__ row, int V, int ld, float& m_out,
+                                                     float& s_out, int& arg_out, float* red) {
+    float4 x[CTC_ROW_REGS];
+#pragma unroll
+    for (int i = 0; i < CTC_ROW_REGS; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (c < ld) x[i] = *(const float4*)(row + c);
+    }
+    float m = -INFINITY;
+    int idx = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < CTC_ROW_REGS; ++i) {
+        const int c = (i * 256 + threadIdx.x) * 4;
+        if (c + 3 >= V) {
+            if (c + 0 >= V) x[i].x = -INFINITY;
+            if (c + 1 >= V) x[i].y = -INFINITY;
+            if (c + 2 >= V) x[i].z = -INFINITY;
+            x[i].w = -INFINITY;
+        }
+        const float mx = fmaxf(fmaxf(x[i].x, x[i].y), fmaxf(x[i].z, x[i].w));
+        if (mx > m) {
+            m = mx;
+            idx = c + (x[i].x == mx ? 0 : x[i].y == mx ? 1 : x[i].z == mx ? 2 : 3);
+        }
+    }
+    const float gm = block_max(m, red);
+    float s = 0.f;
+    if (gm != -INFINITY) {
+#pragma unroll
+        for (int i = 0; i < CTC_ROW_REGS; ++i)
+            s += __expf(x[i].x - gm) + __expf(x[i].y - gm) + __expf(x[i].z - gm) + __expf(x[i].w - gm);
+    }
+    s_out = block_sum(s, red);
+    const float cand = (m == gm && idx != 0x7fffffff) ? -(float)idx : -INFINITY;
+    const float best = block_max(cand, red);
+    arg_out = best == -INFINITY ? 0 : (int)(-best);
+    m_out = gm;
+}
+
 // ---------------------------------------------------------------- lattice arithmetic (log2 domain)
 // log2(2^a + 2^b + 2^c) and log2(2^a + 2^b) on the raw exp2 / log2 units: the largest term
 // contributes exactly 1, so one exponential fewer than terms
@@ -248,7 +293,10 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
         const T* lr = logits + (long)row * ldl;
         float m, s;
         int am = 0;
-        if (argmax) row_max_sum_arg<T>(lr, V, m, s, am, red);      // uniform branch
+        bool in_regs = false;
+        if constexpr (sizeof(T) == 4) in_regs = ldl <= CTC_ROW_REGS * 1024 && (ldl & 3) == 0;
+        if (in_regs) row_max_sum_arg_regs((const float*)lr, V, ldl, m, s, am, red);     // uniform branches
+        else if (argmax) row_max_sum_arg<T>(lr, V, m, s, am, red);
         else row_max_sum<T>(lr, V, m, s, red);
         if (threadIdx.x == 0) {
             const float ls = __logf(s);
