@@ -128,6 +128,35 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
     const int tcols = (cols + 31) / 32;
     const int local = (int)(tid - tile_prefix[mi]);
     const int tr = local / tcols, tc = local - tr * tcols;
+    // matrices whose dimensions, leading dimensions and offsets are all multiples of four move in
+    // four-element pieces: one 16-byte load, an 8-byte store of the straight copy and an 8-byte
+    // store of the transposed copy per thread
+    const bool vec = ((rows | cols | (int)(ld_s & 3) | (int)(ld_t & 3)) & 3) == 0 && ((src | dst | dst_t) & 3) == 0 &&
+                     ((((uintptr_t)params) & 15) | (((uintptr_t)shadow) & 7)) == 0;
+    if (vec) {
+        const int y = threadIdx.x >> 3, x4 = (threadIdx.x & 7) * 4;
+        {
+            const int r = tr * 32 + y, c = tc * 32 + x4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c < cols) {
+                v = *(const float4*)(params + src + (long)r * cols + c);
+                union { bf16_t h[4]; uint2 u; } pk;
+                pk.h[0] = (bf16_t)v.x; pk.h[1] = (bf16_t)v.y; pk.h[2] = (bf16_t)v.z; pk.h[3] = (bf16_t)v.w;
+                *(uint2*)(shadow + dst + (long)r * ld_s + c) = pk.u;
+            }
+            tile[y][x4] = v.x; tile[y][x4 + 1] = v.y; tile[y][x4 + 2] = v.z; tile[y][x4 + 3] = v.w;
+        }
+        __syncthreads();
+        // transposed copy: row index c of the original columns, four consecutive original rows
+        const int c = tc * 32 + y, r = tr * 32 + x4;
+        if (r < rows && c < cols) {
+            union { bf16_t h[4]; uint2 u; } pk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)tile[x4 + k][y];
+            *(uint2*)(shadow + dst_t + (long)c * ld_t + r) = pk.u;
+        }
+        return;
+    }
     const int x = threadIdx.x & 31, y0 = threadIdx.x >> 5;    // 32 x 8
     for (int y = y0; y < 32; y += 8) {
         const int r = tr * 32 + y, c = tc * 32 + x;
