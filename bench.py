@@ -242,6 +242,9 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     if world > 1 or os.environ.get("ATHENA_FORCE_DP", "0") == "1":
+        # a forced single-process data-parallel run outside a launcher rendezvouses with itself
+        for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(key, val)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
