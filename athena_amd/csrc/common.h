@@ -85,23 +85,25 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ---------------------------------------------------------------- activations
 __device__ __forceinline__ float relu6f(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
-// tanh-form GELU and its derivative; tanh(u) = 1 - 2/(exp(2u)+1) on the fast exp/divide units
-__device__ __forceinline__ float fast_tanh_f(float u) {
-    const float e = __expf(2.f * u);          // inf for large u -> 1 - 0; 0 for very negative u -> -1
-    return 1.f - __fdividef(2.f, e + 1.f);
-}
+// tanh-form GELU and its derivative.  0.5 x (1 + tanh(u)) = x sigmoid(2u) = x - x / (exp(2u) + 1) with
+// u = sqrt(2/pi) (x + 0.044715 x^3): one exp2 and one reciprocal on the fast units, the constants
+// of 2u (and log2(e)) folded into one polynomial in x^2.  exp2 = inf gives x, exp2 = 0 gives 0.
+#define GELU_K0 2.3022082f          // 2 sqrt(2/pi) log2(e)
+#define GELU_K1 0.10294324f         // 2 sqrt(2/pi) 0.044715 log2(e)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float c = 0.7978845608028654f;
-    float u = c * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.f + fast_tanh_f(u));
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(fmaf(x2, GELU_K1, GELU_K0) * x);
+    const float r = __builtin_amdgcn_rcpf(e + 1.f);
+    return fmaf(-x, r, x);
 }
+// d/dx [x s] = s + x s (1 - s) (2u)' with s = sigmoid(2u) = 1 - r, (2u)' = 2 sqrt(2/pi) (1 + 3 * 0.044715 x^2)
 __device__ __forceinline__ float dgelu_tanh_f(float x) {
-    const float c = 0.7978845608028654f;
-    float x2 = x * x;
-    float u = c * (x + 0.044715f * x * x2);
-    float t = fast_tanh_f(u);
-    float du = c * (1.f + 3.f * 0.044715f * x2);
-    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(fmaf(x2, GELU_K1, GELU_K0) * x);
+    const float r = __builtin_amdgcn_rcpf(e + 1.f);
+    const float sg = 1.f - r;
+    const float du2 = fmaf(x2, 0.21406445f, 1.5957691f);      // 6 sqrt(2/pi) 0.044715, 2 sqrt(2/pi)
+    return fmaf(x * sg * r, du2, sg);
 }
 
 // ---------------------------------------------------------------- counter-based RNG for dropout
