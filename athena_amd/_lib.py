@@ -86,6 +86,7 @@ _SIGNATURES = {
     "athena_ctc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "athena_ctc_loss_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                     c_size_t, _S]),
+    "athena_ctc_loss_fwd_static": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_ctc_loss_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float,
                                     _P, c_int, _P, c_size_t, _S]),
     "athena_ce_loss_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _S]),

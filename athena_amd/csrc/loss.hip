@@ -11,6 +11,8 @@
 //                into an LDS accumulator, then grad = scale * (softmax - occupancy) streamed out
 #include "common.h"
 
+#include <mutex>
+
 #define CTC_LOGZERO (-1e30f)
 #define CTC_MAX_R 16            // lattice states per lane: supports 2U+1 <= 1024
 #define CTC_LOG2E 1.4426950408889634f
@@ -33,6 +35,7 @@ struct CtcWorkspace {
     float* alpha;    // [B*T*Sp]  log2 alpha up to a per-(b,t) constant (emission at t included)
     float* beta;     // [B*T*Sp]  log2 beta  up to a per-(b,t) constant (emission at t excluded)
     double* ll;      // [B]       log2 of the path sum over blank-relative emissions (-inf: no path)
+    int32_t* flags;  // [B]       1: no alignment fits; alpha / beta then hold TensorFlow's leaky lattice
     int Sp;          // row pitch of alpha / beta: 64 * states per lane
 };
 
@@ -52,6 +55,8 @@ static size_t ctc_ws_layout(int B, int T, int U, void* base, CtcWorkspace* ws) {
     off += n_lat;
     if (ws) ws->ll = (double*)(p + off);
     off += align_up(sizeof(double) * (size_t)B, 256);
+    if (ws) ws->flags = (int32_t*)(p + off);
+    off += align_up(sizeof(int32_t) * (size_t)B, 256);
     if (ws) ws->Sp = Sp;
     return off;
 }
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = threadIdx.x >> 6;
-    const int L = label_len[b];
+    const int L = min(max(label_len[b], 0), U);
     const int Sb = 2 * L + 1;
     int len = logit_len[b];
     if (len > T_) len = T_;
@@ -493,24 +498,183 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logi
     }
 }
 
-// loss[b] = -(ln of the blank-relative path sum - sum over t of (lse - logit[blank])); one wave per sample
-__global__ __launch_bounds__(64) void ctc_finish_kernel(const int32_t* __restrict__ label_len,
-                                                        const int32_t* __restrict__ logit_len, int T_,
-                                                        const float* __restrict__ nrm, const double* __restrict__ ll,
-                                                        float* __restrict__ loss) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// TensorFlow's dense CTC starts its forward vector at log(1e-307) (cast to fp32) instead of log 0
+// on every state but the start state, and ends its backward vector the same way on every state but
+// the two final ones.  Where an alignment exists these leaks change nothing (1e-307 relative);
+// where none exists they ARE the result: a finite loss of about 7e2 and a gradient that follows
+// the leaked paths.
+#define CTC_TF_LOG0 (-706.8936157226562)
+
+__device__ __forceinline__ double lse_pair(double a, double b) {
+    const double m = fmax(a, b);
+    if (m == -(double)INFINITY) return m;
+    return m + log(exp(a - m) + exp(b - m));
+}
+
+// loss[b] = -(ln of the blank-relative path sum - sum over t of (lse - logit[blank])); one workgroup
+// per sample, of which one wave does this sum.
+//
+// A sample whose labels do not fit its frames (path sum zero) takes the slow path instead, on all
+// four waves: tf.nn.ctc_loss's dense recursion restated literally for that sample (reference call
+// site athena/loss.py:38-45) -- every one of the U label states and U+1 blank states of the padded
+// label row plus the silent start state, the leaky initial and final vectors, the loss read from the
+// backward recursion -- in double precision, states in LDS.  It overwrites the sample's alpha / beta
+// rows with that lattice (same state order: even = blank, odd = label; log2 units; shifted by the
+// row maximum) and raises flags[b], which tells ctc_grad to walk all 2U+1 states.
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_finish_kernel(const T* __restrict__ logits, int ldl,
+                                                         const int32_t* __restrict__ labels,
+                                                         const int32_t* __restrict__ label_len,
+                                                         const int32_t* __restrict__ logit_len, int T_, int V,
+                                                         int U, int blank, int Sp, const float* __restrict__ lse,
+                                                         const float* __restrict__ nrm, float* __restrict__ alpha,
+                                                         float* __restrict__ beta, const double* __restrict__ ll,
+                                                         int32_t* __restrict__ flags, float* __restrict__ loss) {
+    __shared__ double st[2][64 * CTC_MAX_R];
+    __shared__ float red[32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     int len = logit_len[b];
     if (len > T_) len = T_;
-    double acc = 0.0;
-    for (int t = lane; t < len; t += 64) acc += (double)nrm[(long)b * T_ + t];
+    const int L = min(max(label_len[b], 0), U);
+    if (len <= 0) {
+        // no frames: TensorFlow reads the loss off its final vector at the start state
+        if (tid == 0) {
+            loss[b] = L == 0 ? 0.f : (float)(-CTC_TF_LOG0);
+            flags[b] = 0;
+        }
+        return;
+    }
+    const double llb = ll[b];
+    if (llb != -(double)INFINITY) {
+        if (tid >= 64) return;
+        double acc = 0.0;
+        for (int t = lane; t < len; t += 64) acc += (double)nrm[(long)b * T_ + t];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) {
-        float out;
-        if (len <= 0) out = label_len[b] == 0 ? 0.f : -CTC_LOGZERO;
-        else if (ll[b] == -(double)INFINITY) out = -CTC_LOGZERO;     // no alignment fits: finite log-zero
-        else out = (float)(acc - ll[b] * CTC_LN2);
-        loss[b] = out;
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            loss[b] = (float)(acc - llb * CTC_LN2);
+            flags[b] = 0;
+        }
+        return;
+    }
+    // ---------------- slow path
+    const int S2 = 2 * U + 1;
+    const T* lb = logits + (long)b * T_ * ldl;
+    const int32_t* lab = labels + (long)b * U;
+    constexpr int PER = (64 * CTC_MAX_R) / 256;
+    int cls[PER];
+    bool skip_in[PER], skip_out[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + 256 * i;
+        int c = blank;
+        bool si = false, so = false;
+        if (s < S2 && (s & 1)) {
+            const int u = s >> 1;
+            c = lab[u];
+            if (u >= 1) si = c != lab[u - 1];
+            if (u + 1 < U) so = lab[u + 1] != c;
+        }
+        cls[i] = (c >= 0 && c < V) ? c : blank;
+        skip_in[i] = si;
+        skip_out[i] = so;
+    }
+    auto emission = [&](int t, int i) -> double {
+        return (double)to_f32<T>(lb[(long)t * ldl + cls[i]]) - (double)lse[(long)b * T_ + t];
+    };
+    float* ab = alpha + (long)b * T_ * Sp;
+    float* bb = beta + (long)b * T_ * Sp;
+    // forward: fwd[t+1][s] = lse over predecessors of fwd[t] + emission at t
+    double start = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) st[0][tid + 256 * i] = CTC_TF_LOG0;
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < len; ++t) {
+        double nv[PER];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            nv[i] = -(double)INFINITY;
+            if (s < S2) {
+                double v = st[cur][s];
+                if (s >= 1) v = lse_pair(v, st[cur][s - 1]);
+                if (skip_in[i]) v = lse_pair(v, st[cur][s - 2]);
+                if (s <= 1) v = lse_pair(v, start);          // start -> blank 0, start -> label 1
+                nv[i] = v + emission(t, i);
+                mx = fmaxf(mx, (float)nv[i]);
+            }
+        }
+        mx = block_max(mx, red);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            if (s < S2) {
+                const double v = nv[i] - (double)mx;
+                st[cur ^ 1][s] = v;
+                ab[(long)t * Sp + s] = fmaxf((float)(v * (double)CTC_LOG2E), CTC_LOGZERO);
+            }
+        }
+        start = -(double)INFINITY;                           // the start state emits nothing
+        cur ^= 1;
+        __syncthreads();
+    }
+    // backward: bwd[len] = final vector; bwd[t] = lse over successors of (bwd[t+1] + emission at t)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = tid + 256 * i;
+        const bool fin = s == 2 * L || (L >= 1 && s == 2 * L - 1);
+        st[0][s] = fin ? 0.0 : CTC_TF_LOG0;
+    }
+    double bstart = L == 0 ? 0.0 : CTC_TF_LOG0;
+    double cum = 0.0;
+    cur = 0;
+    __syncthreads();
+    for (int t = len - 1; t >= 0; --t) {
+        // beta[t] = bwd[t+1]
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            if (s < S2) bb[(long)t * Sp + s] = fmaxf((float)(st[cur][s] * (double)CTC_LOG2E), CTC_LOGZERO);
+        }
+        // w[s] = bwd[t+1][s] + emission at t, parked in the other buffer
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            if (s < S2) st[cur ^ 1][s] = st[cur][s] + emission(t, i);
+        }
+        __syncthreads();
+        double nv[PER];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            nv[i] = -(double)INFINITY;
+            if (s < S2) {
+                double v = st[cur ^ 1][s];
+                if (s + 1 < S2) v = lse_pair(v, st[cur ^ 1][s + 1]);
+                if (skip_out[i]) v = lse_pair(v, st[cur ^ 1][s + 2]);
+                nv[i] = v;
+                mx = fmaxf(mx, (float)v);
+            }
+        }
+        double ns = st[cur ^ 1][0];                          // start -> blank 0
+        if (S2 > 1) ns = lse_pair(ns, st[cur ^ 1][1]);       // start -> label 1
+        mx = fmaxf(mx, (float)ns);
+        mx = block_max(mx, red);                             // (its barriers also end the reads of w)
+        cum += (double)mx;
+        bstart = ns - (double)mx;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int s = tid + 256 * i;
+            if (s < S2) st[cur][s] = nv[i] - (double)mx;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        loss[b] = (float)(-(bstart + cum));
+        flags[b] = 1;
     }
 }
 
@@ -560,6 +724,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const TL* __restrict__ lo
                                                        int blank, int Sp, const float* __restrict__ lse,
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta,
+                                                       const int32_t* __restrict__ flags,
                                                        const float* __restrict__ grad_scale, float host_scale,
                                                        TG* __restrict__ grad, int rows_total, int chunk) {
     extern __shared__ float occ[];       // [chunk]
@@ -575,7 +740,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const TL* __restrict__ lo
             for (int c = threadIdx.x * 4; c < ldl; c += blockDim.x * 4) ctc_store4<TG>(gr + c, 0.f, 0.f, 0.f, 0.f);
             continue;
         }
-        const int Sb = 2 * label_len[b] + 1;
+        // a sample without a fitting alignment carries TensorFlow's lattice over the whole padded label row
+        const int Sb = flags[b] ? 2 * U + 1 : 2 * min(max(label_len[b], 0), U) + 1;
         const float* ar = alpha + (long)row * Sp;
         const float* br = beta + (long)row * Sp;
         const TL* lr = logits + (long)row * ldl;
@@ -676,9 +842,63 @@ extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl
         dispatch_ctc_fwd<bf16_t>(R, (const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
     else
         dispatch_ctc_fwd<float>(R, (const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
-    hipLaunchKernelGGL(ctc_finish_kernel, dim3(B), dim3(64), 0, s, label_len, logit_len, T, ws.nrm, ws.ll, loss);
+    if (logits_dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(ctc_finish_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, ldl, labels,
+                           label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll,
+                           ws.flags, loss);
+    else
+        hipLaunchKernelGGL(ctc_finish_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, ldl, labels,
+                           label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll,
+                           ws.flags, loss);
     ATHENA_CHECK_LAUNCH("athena_ctc_loss_fwd");
     return ATHENA_OK;
+}
+
+// ---------------------------------------------------------------- allocation-free forward
+// athena_ctc_loss_fwd with its workspace in a device array of this library instead of a caller
+// buffer, for callers that cannot allocate device memory (a stream under graph capture, a serving
+// loop).  ``scratch`` names the array for the device compiler only: in host code that name is a
+// stand-in, not a device address, so the address of each GPU's copy is asked of the runtime once
+// per device and that pointer is what the kernels receive.
+#define CTC_STATIC_SCRATCH_BYTES ((size_t)16 << 20)
+#define CTC_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[CTC_STATIC_SCRATCH_BYTES];
+static void* g_scratch_ptr[CTC_STATIC_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// address of the current device's copy of ``scratch`` (resolved at the first call on that device)
+static int ctc_static_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    ATHENA_REQUIRE(e == hipSuccess && dev >= 0 && dev < CTC_STATIC_MAX_DEVICES, ATHENA_E_LAUNCH,
+                   "athena_ctc_loss_fwd_static: hipGetDevice failed or device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        ATHENA_REQUIRE(e == hipSuccess && ptr, ATHENA_E_LAUNCH,
+                       "athena_ctc_loss_fwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return ATHENA_OK;
+}
+
+extern "C" int athena_ctc_loss_fwd_static(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
+                                          const int32_t* label_len, const int32_t* logit_len, int B, int T, int V,
+                                          int U, int blank, float* loss, int32_t* argmax, athena_stream_t stream) {
+    ATHENA_REQUIRE(B > 0 && T > 0 && U >= 0, ATHENA_E_SHAPE, "athena_ctc_loss_fwd_static: bad shape B=%d T=%d U=%d", B, T, U);
+    const size_t need = athena_ctc_workspace_bytes(B, T, U);
+    ATHENA_REQUIRE(need <= CTC_STATIC_SCRATCH_BYTES, ATHENA_E_UNSUPPORTED,
+                   "athena_ctc_loss_fwd_static: B=%d T=%d U=%d needs %zu bytes of scratch, the built-in buffer holds %zu; "
+                   "use athena_ctc_loss_fwd with a caller workspace", B, T, U, need, (size_t)CTC_STATIC_SCRATCH_BYTES);
+    void* ws = nullptr;
+    int rc = ctc_static_scratch(&ws);
+    if (rc) return rc;
+    // every word of the workspace that the kernels read they have written earlier in the same
+    // call, so nothing of a previous call has to be cleared
+    return athena_ctc_loss_fwd(logits, logits_dtype, ldl, labels, label_len, logit_len, B, T, V, U, blank, loss, argmax,
+                               ws, CTC_STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int athena_ctc_loss_bwd(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
@@ -701,7 +921,7 @@ extern "C" int athena_ctc_loss_bwd(const void* logits, int logits_dtype, int ldl
 #define CTC_GRAD(TL, TG)                                                                                          \
     hipLaunchKernelGGL((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), chunk * sizeof(float), s,                \
                        (const TL*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse,       \
-                       ws.alpha, ws.beta, grad_scale, host_scale, (TG*)grad, rows, chunk)
+                       ws.alpha, ws.beta, ws.flags, grad_scale, host_scale, (TG*)grad, rows, chunk)
     if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CTC_GRAD(float, float);
     else if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_BF16) CTC_GRAD(float, bf16_t);
     else if (logits_dtype == ATHENA_BF16 && grad_dtype == ATHENA_BF16) CTC_GRAD(bf16_t, bf16_t);
@@ -734,7 +954,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
         lse[row] = l;
         float loss = 0.f;
         if (tgt != 0) {
-            const float lp_t = to_f32<T>(lr[tgt]) - l;
+            // a target outside [0, V) has an all-zero one-hot row (tf.one_hot), it is never dereferenced
+            const float lp_t = (tgt > 0 && tgt < V) ? to_f32<T>(lr[tgt]) - l : 0.f;
             loss = -(1.f - ls) * lp_t;
             if (ls != 0.f) loss -= (ls / V) * (sx - (float)V * l);
         }
@@ -759,11 +980,12 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* __restrict__ logi
     const TL* lr = logits + (long)row * ldl;
     const float l = lse[row];
     const float uni = ls / V;
-    // sum_v y_v = (1-ls) + V*ls/V = 1
+    // sum_v y_v = (1-ls) + V*ls/V = 1 (only ls for a target outside [0, V), whose one-hot row is empty)
+    const float sum_y = (tgt > 0 && tgt < V) ? 1.f : ls;
     for (int c = threadIdx.x; c < V; c += blockDim.x) {
         const float p = __expf(to_f32<TL>(lr[c]) - l);
         const float y = uni + (c == tgt ? 1.f - ls : 0.f);
-        gr[c] = from_f32<TG>(scale * (p - y));
+        gr[c] = from_f32<TG>(scale * (p * sum_y - y));
     }
     for (int c = V + threadIdx.x; c < ldl; c += blockDim.x) gr[c] = from_f32<TG>(0.f);
 }

@@ -73,9 +73,15 @@ class SyntheticSpeechRecognitionDatasetBuilder:
         return len(self.order)
 
     def shard(self, num_shards, index):
-        """Keep every ``num_shards``-th utterance starting at ``index`` (base.py:126-138)."""
-        if num_shards > 1:
-            self.order = self.order[index::num_shards]
+        """Keep every ``num_shards``-th utterance starting at ``index``, after trimming the list to a
+        multiple of ``num_shards`` so that every rank gets the same count and therefore the same
+        number of steps (and collectives) per epoch (base.py:126-138)."""
+        if num_shards <= 1:
+            return self
+        if not 0 <= index < num_shards:
+            raise ValueError("shard: index %d outside [0, %d)" % (index, num_shards))
+        total = (len(self.order) // num_shards) * num_shards
+        self.order = self.order[:total][index::num_shards]
         return self
 
     def batch_wise_shuffle(self, batch_size=64):

@@ -595,7 +595,7 @@ def bf16_grad_wanted(logits):
 
 
 def bf16_grad_standin(shape, g16):
-    s = torch.empty(1, dtype=torch.float32, device=g16.device)
+    s = torch.zeros(1, dtype=torch.float32, device=g16.device)     # a second consumer of the logits sees zeros, not noise
     # the entry keeps the stand-in's storage alive, so no other tensor can have its address
     # while the entry exists
     _BF16_GRADS[s.data_ptr()] = (s, g16)

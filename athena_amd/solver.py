@@ -107,13 +107,32 @@ class BaseSolver:
         if not self._graphable(samples):
             return self._eager_step(samples)
         key = _shape_key(samples)
-        state = self._graphs.get(key)
+        state = self._graphs.pop(key, None)
         if state is None:                    # first sight of this shape: plain step (also the warm-up)
             self._graphs[key] = False
+            self._trim_graphs()
             return self._eager_step(samples)
         if state is False:
-            state = self._graphs[key] = self._record(samples)
+            state = self._record(samples)
+        self._graphs[key] = state            # most recently used last
+        self._trim_graphs()
         return state.run(samples)
+
+    # Recorded steps kept at a time.  Every recorded shape holds the intermediates of a whole step in
+    # the graphs' memory pool (shared by all graphs of this solver, so the blocks of an evicted
+    # graph serve the next recording); batches padded to their own longest utterance produce
+    # hundreds of shapes per epoch, of which only the most recently used ones stay recorded.
+    MAX_GRAPHS = int(os.environ.get("ATHENA_MAX_GRAPHS", "24"))
+
+    def _trim_graphs(self):
+        while len(self._graphs) > max(self.MAX_GRAPHS, 1):
+            oldest = next(iter(self._graphs))
+            del self._graphs[oldest]         # a shape seen again later starts over with an eager step
+
+    def _graph_pool(self):
+        if getattr(self, "_pool", None) is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        return self._pool
 
     def _record(self, samples):
         return _GraphStep(self, samples)
@@ -132,8 +151,10 @@ class BaseSolver:
                 break
             samples = self.model.prepare_samples(samples)
             loss, metrics = self.train_step(samples)
-            if batch % self.hparams.log_interval == 0 and self.rank == 0:
-                logging.info(self.metric_checker(loss, metrics))
+            if batch % self.hparams.log_interval == 0:
+                # every rank drops its queued metric updates here; only rank 0 reports them
+                if self.rank == 0:
+                    logging.info(self.metric_checker(loss, metrics))
                 self.model.reset_metrics()
 
     def evaluate_step(self, samples):
@@ -192,14 +213,17 @@ class _GraphStep:
         split = solver.world_size > 1 or getattr(solver, "_force_exchange", False)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+        # the recorded forward pass always starts by rebuilding the bf16 weight copies: whether the
+        # host flag happens to be set while recording must not decide what every replay does
+        solver.model.store.shadows_dirty = True
+        with torch.cuda.graph(self.graph, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE):
             self.loss, self.metrics = solver._forward_backward(self.inputs)
             if not split:
                 solver._update(1.0)
         self.update_graph = None
         if split:
             self.update_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.update_graph, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self.update_graph, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE):
                 solver._update(1.0 / solver.world_size)
         # the deferred scorers queued while recording become templates
         self.templates = []
@@ -215,6 +239,8 @@ class _GraphStep:
         if self.update_graph is not None:
             self.solver._reduce_gradients()
             self.update_graph.replay()
+        # the replayed update changed the weights behind the host's back
+        self.solver.model.store.shadows_dirty = True
         for m, items in self.templates:
             for t in items:
                 m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
@@ -241,8 +267,10 @@ class _PipelinedGraphStep:
         self.graphs = []
         g0 = torch.cuda.CUDAGraph()
         store.collect_cuts = True
+        store.shadows_dirty = True          # the refresh is always part of the recorded forward pass
         try:
-            with torch.cuda.graph(g0, capture_error_mode=_CAPTURE_MODE), ops.bf16_grad_handover():
+            with torch.cuda.graph(g0, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE), \
+                    ops.bf16_grad_handover():
                 outputs = solver.model(self.inputs, training=True)
                 self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
                 total = sum(list(self.loss.values())) if isinstance(self.loss, dict) else self.loss
@@ -292,6 +320,7 @@ class _PipelinedGraphStep:
             if w is not None:
                 w.wait()
         self.update_graph.replay()
+        self.solver.model.store.shadows_dirty = True
         for m, items in self.templates:
             for t in items:
                 m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
@@ -439,6 +468,7 @@ class HorovodSolver(BaseSolver):
             loss, metrics = self.train_step(samples)
             if batch == 0 and not self._broadcast_done:
                 self.broadcast_variables()
-            if batch % self.hparams.log_interval == 0 and self.rank == 0:
-                logging.info(self.metric_checker(loss, metrics))
+            if batch % self.hparams.log_interval == 0:
+                if self.rank == 0:
+                    logging.info(self.metric_checker(loss, metrics))
                 self.model.reset_metrics()

@@ -335,9 +335,14 @@ def test_synthetic_dataset_builder_batches_shards_and_shuffles():
     # sorted by duration before the first shuffle
     lens = [int(x) for s in batches for x in s["input_length"]]
     assert lens == sorted(lens)
-    # shards are disjoint and cover the set
+    # shards are disjoint, equally long (37 utterances over 3 ranks: 12 each, the last one dropped, as
+    # reference base.py:134 does, so that every rank runs the same number of steps)
     parts = [Builder(cfg).shard(3, r) for r in range(3)]
-    assert sorted(i for p in parts for i in p.order) == list(range(37))
+    assert [len(p.order) for p in parts] == [12, 12, 12]
+    full = Builder(cfg).order
+    assert sorted(i for p in parts for i in p.order) == sorted(full[:36])
+    with pytest.raises(ValueError):
+        Builder(cfg).shard(3, 3)
     # a batch-wise shuffle permutes whole batches and keeps every utterance
     before = list(b.order)
     b.batch_wise_shuffle(8)

@@ -575,15 +575,77 @@ def test_ctc_matches_brute_force(ops):
         assert_close(per, torch.tensor(case["loss"]), 1e-5, "brute-force KAT")
 
 
-def test_ctc_infeasible_is_large_finite(ops):
-    B, T, V, U = 1, 3, 5, 4      # 4 labels cannot fit in 3 frames
-    buf = torch.zeros(B, T, 8, device=dev())
+def _run_ctc(ops, logits, labels, llen, tlen, gscale=1.0):
+    """(per-sample loss, gradient [B,T,V]) of the HIP kernels on fp32 logits [B,T,V]."""
+    B, T, V = logits.shape
+    U = labels.shape[1]
+    ldl = (V + 7) // 8 * 8
+    buf = torch.zeros(B, T, ldl, dtype=torch.float32, device=dev())
+    buf[..., :V] = torch.as_tensor(logits).float().to(dev())
     ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev())
+    per = torch.empty(B, dtype=torch.float32, device=dev())
+    lab_d = torch.as_tensor(labels, dtype=torch.int32).to(dev())
+    ll_d = torch.as_tensor(llen, dtype=torch.int32).to(dev())
+    tl_d = torch.as_tensor(tlen, dtype=torch.int32).to(dev())
+    ops.ctc_loss_fwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, U, V - 1, per, ws)
+    grad = torch.full((B, T, ldl), float("nan"), dtype=torch.float32, device=dev())
+    ops.ctc_loss_bwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, U, V - 1, None, gscale, grad, ws)
+    return per, grad[..., :V]
+
+
+def test_ctc_infeasible_matches_tf_dense(ops):
+    """Samples whose labels do not fit their frames: tf.nn.ctc_loss's dense branch starts and ends
+    its state vectors at log(1e-307) instead of log 0, so it returns a finite loss of about 7e2 and
+    a gradient along the leaked paths.  Loss and gradient must equal the restatement of that
+    branch (oracle.ctc.ctc_loss_tf_dense), also when feasible and infeasible samples share a batch
+    and when a sample has no frames at all."""
+    rng = np.random.default_rng(11)
+    B, T, V, U = 6, 7, 6, 5
+    logits = np.float32(rng.normal(size=(B, T, V)) * 1.5)
+    labels = np.array([[1, 2, 3, 1, 2],      # 5 labels, 3 frames
+                       [2, 2, 2, 0, 0],      # 3 equal labels need 5 frames, has 4
+                       [1, 3, 0, 0, 0],      # fits
+                       [4, 4, 1, 1, 0],      # 4 labels with two repeats need 6 frames, has 5
+                       [3, 1, 2, 0, 0],      # no frames at all
+                       [0, 0, 0, 0, 0]],     # no labels, no frames
+                      dtype=np.int32)
+    llen = np.array([5, 3, 2, 4, 3, 0], np.int32)
+    tlen = np.array([3, 4, 7, 5, 0, 0], np.int32)
+    loss_ref, grad_ref = octc.ctc_loss_tf_dense(logits.astype(np.float64), labels, llen, tlen, blank_index=-1)
+    assert loss_ref[0] > 500 and loss_ref[1] > 500 and loss_ref[2] < 50 and loss_ref[3] > 500
+    per, grad = _run_ctc(ops, logits, labels, llen, tlen)
+    assert_close(per, loss_ref, 1e-5, "ctc loss, TF dense semantics")
+    for b in range(B):
+        if tlen[b] > 0:
+            assert_close(grad[b], grad_ref[b], 1e-4, "ctc grad, TF dense semantics, sample %d" % b)
+        else:
+            assert float(grad[b].abs().max()) == 0.0
+    # a longer infeasible lattice (several states per lane, many steps)
+    B, T, V, U = 2, 60, 40, 70
+    logits = np.float32(rng.normal(size=(B, T, V)) * 2.0)
+    labels = rng.integers(1, V - 1, size=(B, U)).astype(np.int32)
+    llen = np.array([70, 20], np.int32)
+    labels[1, 20:] = 0
+    tlen = np.array([60, 60], np.int32)
+    loss_ref, grad_ref = octc.ctc_loss_tf_dense(logits.astype(np.float64), labels, llen, tlen, blank_index=-1)
+    assert loss_ref[0] > 500 and loss_ref[1] < 500
+    per, grad = _run_ctc(ops, logits, labels, llen, tlen)
+    assert_close(per, loss_ref, 1e-5, "ctc loss, TF dense semantics (long)")
+    for b in range(B):
+        assert_close(grad[b], grad_ref[b], 1e-4, "ctc grad, TF dense semantics (long), sample %d" % b)
+
+
+def test_ctc_label_row_too_long_is_refused(ops):
+    """Label rows beyond 2U+1 = 1024 lattice states are refused with a clear error, not truncated."""
+    B, T, V, U = 1, 8, 16, 600
+    buf = torch.zeros(B, T, V, device=dev())
+    assert ops.ctc_workspace_bytes(B, T, 511) > 0
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev())
     per = torch.empty(B, device=dev())
-    ops.ctc_loss_fwd(buf, 8, torch.tensor([[1, 2, 3, 1]], dtype=torch.int32).to(dev()),
-                     torch.tensor([4], dtype=torch.int32).to(dev()), torch.tensor([3], dtype=torch.int32).to(dev()),
-                     B, T, V, U, V - 1, per, ws)
-    assert torch.isfinite(per).all() and float(per[0]) > 1e20
+    with pytest.raises(RuntimeError, match="too long"):
+        ops.ctc_loss_fwd(buf, V, torch.ones(B, U, dtype=torch.int32, device=dev()),
+                         torch.tensor([U], dtype=torch.int32).to(dev()), torch.tensor([T], dtype=torch.int32).to(dev()),
+                         B, T, V, U, V - 1, per, ws)
 
 
 # ------------------------------------------------------------------------------------------ CE / argmax

@@ -147,6 +147,60 @@ def test_graph_replay_matches_eager_steps(precision):
     assert worst <= (1e-4 if precision == "fp32" else 2e-2), worst
 
 
+def test_graph_replay_with_evaluations_and_two_shapes_matches_eager():
+    """bf16 mode keeps bf16 copies of the weights that must be rebuilt after every update.  A step
+    recorded right after an evaluation (which leaves the copies fresh), replays of two shapes in
+    turn, and an evaluation right after a replay must all see the latest weights: the whole
+    sequence follows the eager trajectory.  Also: the recorded-shape cache stays within its cap."""
+    from athena_amd import BaseSolver, WarmUpAdam
+    from tests.modelutil import model_config
+    case = dict(TINY, mc=model_config(32, 16, 4, 2, 1, 64, rate=0.0, ls=0.1))
+    opt_cfg = dict(d_model=32, warmup_steps=2, k=0.3, decay_steps=100000, decay_rate=1.0)
+    runs = {}
+    for graph in (False, True):
+        model, samples, _ = build(case, "bf16")
+        opt = WarmUpAdam(dict(opt_cfg))
+        solver = BaseSolver(model, opt, config={"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": graph})
+        a = model.prepare_samples(samples)
+        short = {k: v.clone() for k, v in samples.items()}
+        short["input"] = short["input"][:, :-8].contiguous()
+        short["input_length"] = short["input_length"].clamp(max=short["input"].shape[1])
+        b = model.prepare_samples(short)
+        trace = []
+        # shape a: eager warm-up, evaluation, recording (right after the evaluation), replay
+        trace.append(float(solver.train_step(a)[0]))
+        trace.append(float(solver.evaluate_step(a)[0]))
+        trace.append(float(solver.train_step(a)[0]))
+        trace.append(float(solver.train_step(a)[0]))
+        # shape b in between: eager, evaluation, recording, then both shapes replayed in turn
+        trace.append(float(solver.train_step(b)[0]))
+        trace.append(float(solver.evaluate_step(b)[0]))
+        trace.append(float(solver.train_step(b)[0]))
+        for batch in (a, b, a, b):
+            trace.append(float(solver.train_step(batch)[0]))
+        # an evaluation right after a replay scores the updated weights
+        trace.append(float(solver.evaluate_step(a)[0]))
+        runs[graph] = trace
+        if graph:
+            assert sum(1 for v in solver._graphs.values() if v not in (None, False)) == 2
+    for i, (x, y) in enumerate(zip(runs[False], runs[True])):
+        assert abs(x - y) <= 2e-3 * max(1.0, abs(x)), (i, runs[False], runs[True])
+    # the cap on recorded shapes: the least recently used one is dropped
+    model, samples, _ = build(case, "bf16")
+    solver = BaseSolver(model, WarmUpAdam(dict(opt_cfg)),
+                        config={"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": True})
+    solver.MAX_GRAPHS = 2
+    for cut in (0, 4, 8, 12):
+        sh = {k: v.clone() for k, v in samples.items()}
+        if cut:
+            sh["input"] = sh["input"][:, :-cut].contiguous()
+            sh["input_length"] = sh["input_length"].clamp(max=sh["input"].shape[1])
+        d = model.prepare_samples(sh)
+        for _ in range(3):
+            assert torch.isfinite(solver.train_step(d)[0])
+        assert len(solver._graphs) <= 2
+
+
 def test_data_parallel_step_structure_on_one_gpu():
     """The data-parallel step (forward/backward graph -> gradient exchange -> update graph with the
     1/world_size factor) with the exchange replaced by "the other rank had the same gradients":
