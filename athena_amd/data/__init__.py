@@ -1,4 +1,3 @@
-"""Dataset builders of the training entry point (reference athena/data/__init__.py)."""
-from .synthetic import SyntheticSpeechRecognitionDatasetBuilder
-
-__all__ = ["SyntheticSpeechRecognitionDatasetBuilder"]
+"""Data side of the training step: the synthetic dataset builder and fixed-shape synthetic batches."""
+from .synthetic import (DataDescriptions, SyntheticSpeechRecognitionDatasetBuilder, make_samples,  # noqa: F401
+                        model_config)

@@ -118,3 +118,54 @@ class SyntheticSpeechRecognitionDatasetBuilder:
                         "output": torch.from_numpy(y),
                         "output_length": torch.tensor([l.shape[0] for _, l in chunk], dtype=torch.int32)})
         return out
+
+
+# ---- fixed-shape synthetic batches and model configurations (benchmark, smoke test, parity tests) ----
+class DataDescriptions:
+    """The part of a dataset builder that the models read (reference
+    athena/data/datasets/speech_recognition.py:134-206): ``num_class``, ``sample_shape`` and
+    ``hparams.text_config`` / ``hparams.words``."""
+
+    class _HP:
+        def __init__(self):
+            self.text_config = {"type": "vocab", "model": None}
+            self.words = None
+
+    def __init__(self, num_class, feat_dim, in_channels=1):
+        self.num_class = num_class
+        self.sample_shape = {"input": (None, feat_dim, in_channels), "input_length": (), "output": (None,),
+                             "output_length": ()}
+        self.hparams = self._HP()
+
+
+def model_config(d_model, num_filters, heads, enc, dec, dff, rate=0.0, mtl_weight=0.5, ls=0.0, **extra):
+    """``model_config`` of ``mtl_transformer_ctc`` in the shape of the shipped recipes
+    (examples/asr/*/configs/mtl_transformer_sp.json); ``extra`` goes into the inner model_config."""
+    inner = {"return_encoder_output": True, "num_filters": num_filters, "d_model": d_model, "num_heads": heads,
+             "num_encoder_layers": enc, "num_decoder_layers": dec, "dff": dff, "rate": rate,
+             "label_smoothing_rate": ls}
+    inner.update(extra)
+    return {"model": "speech_transformer", "model_config": inner, "mtl_weight": mtl_weight}
+
+
+def make_samples(B, T, feat_dim, V, U, seed=1, full_length=True, dtype=torch.float32, in_channels=1):
+    """One synthetic batch of the ``samples`` dict: unit-variance features zeroed beyond
+    ``input_length`` (all T frames, or lengths drawn from [0.6 T, T] and sorted longest first), label
+    ids uniform in [1, V-2] zero-padded beyond ``output_length`` (drawn from [U/2, U]; the first
+    utterance has U labels)."""
+    rng = np.random.default_rng(seed)
+    feats = rng.standard_normal((B, T, feat_dim, in_channels)).astype(np.float32)
+    if full_length:
+        frames = np.full((B,), T, dtype=np.int32)
+    else:
+        frames = np.sort(rng.integers(int(0.6 * T), T + 1, size=B).astype(np.int32))[::-1].copy()
+        frames[0] = T
+    for b in range(B):
+        feats[b, frames[b]:] = 0.0
+    n_labels = rng.integers(max(U // 2, 1), U + 1, size=B).astype(np.int32)
+    n_labels[0] = U
+    ids = rng.integers(1, max(V - 1, 2), size=(B, U)).astype(np.int32)
+    for b in range(B):
+        ids[b, n_labels[b]:] = 0
+    return {"input": torch.from_numpy(feats).to(dtype), "input_length": torch.from_numpy(frames),
+            "output": torch.from_numpy(ids), "output_length": torch.from_numpy(n_labels)}

@@ -40,6 +40,11 @@ WORKLOADS = {
     "aishell_shipped_b32_t1000": dict(B=32, T=1000, feat=40, vocab=4232, U=32, d_model=512, num_filters=512,
                                       heads=8, enc=12, dec=6, dff=1280, rate=0.1,
                                       opt=dict(d_model=512, warmup_steps=25000, k=1.0), clip_norm=100.0),
+    # CTC-heavy stress: encoder + CTC head only carry gradient (no decoder layers, mtl_weight 0: the loss is
+    # the CTC term alone), 8k classes, batch 64, 200 labels per utterance
+    "ctc_heavy_b64": dict(B=64, T=1000, feat=80, vocab=8000, U=200, d_model=256, num_filters=256, heads=4, enc=12,
+                          dec=0, dff=1024, rate=0.1, mtl_weight=0.0,
+                          opt=dict(d_model=256, warmup_steps=25000, k=1.0), clip_norm=100.0),
     "tiny": dict(B=4, T=64, feat=16, vocab=30, U=5, d_model=64, num_filters=32, heads=2, enc=2, dec=1, dff=128,
                  rate=0.1, opt=dict(d_model=64, warmup_steps=10, k=1.0), clip_norm=100.0),
 }
@@ -50,13 +55,31 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 def build(wl, precision, seed):
     from athena_amd import BaseSolver, HorovodSolver, MtlTransformerCtc, WarmUpAdam
-    from tests.modelutil import DataDescriptions, model_config
-    mc = model_config(wl["d_model"], wl["num_filters"], wl["heads"], wl["enc"], wl["dec"], wl["dff"], wl["rate"])
+    from athena_amd.data import DataDescriptions, model_config
+    mc = model_config(wl["d_model"], wl["num_filters"], wl["heads"], wl["enc"], wl["dec"], wl["dff"], wl["rate"],
+                      mtl_weight=wl.get("mtl_weight", 0.5))
     model = MtlTransformerCtc(DataDescriptions(wl["vocab"], wl["feat"]), mc, precision=precision, seed=seed)
     opt = WarmUpAdam(dict(wl["opt"]))
     cfg = {"clip_norm": wl["clip_norm"], "log_interval": 10 ** 9, "enable_tf_function": True}
     solver = (HorovodSolver if dist.is_initialized() else BaseSolver)(model, opt, config=cfg)
     return model, opt, solver, mc
+
+
+def gemm_flops_parts(wl):
+    """Algorithmic FLOPs of one training step (forward x 3) by GEMM family: the implicit-GEMM
+    second convolution, the vocabulary projections, and every other Dense layer (x_net Dense,
+    q/k/v/o projections and FFN of the encoder and decoder layers)."""
+    B, T, Fd = wl["B"], wl["T"], wl["feat"]
+    C, d, dff, V, U = wl["num_filters"], wl["d_model"], wl["dff"], wl["vocab"] + 1, wl["U"]
+    T1, F1 = (T + 1) // 2, (Fd + 1) // 2
+    T2, F2 = (T1 + 1) // 2, (F1 + 1) // 2
+    L = U + 1
+    conv2 = 2 * 9 * C * C * T2 * F2
+    xdense = 2 * F2 * C * d * T2
+    enc = wl["enc"] * (8 * T2 * d * d + 4 * T2 * d * dff)
+    dec = wl["dec"] * (8 * L * d * d + 4 * L * d * d + 4 * T2 * d * d + 4 * L * d * dff)
+    heads = 2 * L * d * V + 2 * T2 * d * V
+    return {"conv2": 3.0 * B * conv2, "layer_gemm": 3.0 * B * (xdense + enc + dec), "vocab": 3.0 * B * heads}
 
 
 def gemm_flops_per_step(wl):
@@ -99,14 +122,17 @@ class KernelTimer:
 
     The entry points are wrapped at the ctypes level, so every launch of the step is seen.  The
     timed step is started behind a spin kernel that keeps the GPU busy while the host enqueues the
-    whole step: the events then bracket back-to-back device execution, not host launch latency."""
+    whole step: the events then bracket back-to-back device execution, not host launch latency.
+    ``classify(name, args)`` names the bucket a call is booked under."""
 
-    def __init__(self, names):
+    def __init__(self, names, classify=None):
         from athena_amd import _lib
         self.lib = _lib.load()
         self.names = names
-        self.pairs = {n: [] for n in names}
+        self.classify = classify or (lambda name, args: name)
+        self.pairs = {}
         self._orig = {}
+        self.floor_ms = 0.0
 
     def __enter__(self):
         for n in self.names:
@@ -118,7 +144,7 @@ class KernelTimer:
                 e0.record()
                 r = _fn(*a)
                 e1.record()
-                self.pairs[_n].append((e0, e1))
+                self.pairs.setdefault(self.classify(_n, a), []).append((e0, e1))
                 return r
             setattr(self.lib, n, wrapped)
         return self
@@ -128,24 +154,38 @@ class KernelTimer:
             setattr(self.lib, n, fn)
 
     def calibrate(self):
-        """Elapsed time of an event pair with nothing between (behind a busy stream): the floor
-        that every measured pair carries, subtracted in total_ms()."""
-        gpu_plug(5.0)
-        pairs = []
-        for _ in range(200):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in pairs)
-        self.floor_ms = ts[len(ts) // 2]
+        """What an event pair adds to the kernels between its two events, measured by difference:
+        behind a busy stream, pairs around ONE tiny kernel take p1 and pairs around TWO take p2, so
+        p2 - p1 is one kernel's slot on the stream and 2 p1 - p2 what the pair itself costs.  That
+        cost is subtracted once per timed launch in total_ms()."""
+        x = torch.zeros(8, dtype=torch.float32, device="cuda")
+        y = torch.zeros(8, dtype=torch.bfloat16, device="cuda")
+        from athena_amd import ops
+
+        def run(k):
+            gpu_plug(5.0)
+            pairs = []
+            for _ in range(200):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(k):
+                    ops.cast(x, y)
+                e1.record()
+                pairs.append((e0, e1))
+            torch.cuda.synchronize()
+            ts = sorted(a.elapsed_time(b) for a, b in pairs)
+            return ts[len(ts) // 2]
+        run(1)
+        p1, p2 = run(1), run(2)
+        self.pair_one_ms, self.pair_two_ms = p1, p2
+        self.floor_ms = max(0.0, 2.0 * p1 - p2)
         return self.floor_ms
 
-    def total_ms(self, names):
+    def total_ms(self, keys):
+        """(milliseconds, launches) of the buckets ``keys``, the per-pair cost taken off."""
         torch.cuda.synchronize()
-        n = sum(len(self.pairs[k]) for k in names)
-        ms = sum(a.elapsed_time(b) for k in names for a, b in self.pairs[k]) - n * getattr(self, "floor_ms", 0.0)
+        n = sum(len(self.pairs.get(k, ())) for k in keys)
+        ms = sum(a.elapsed_time(b) for k in keys for a, b in self.pairs.get(k, ())) - n * self.floor_ms
         return ms, n
 
 
@@ -169,41 +209,64 @@ ATTN_ENTRIES = ["athena_mha_fwd", "athena_mha_bwd"]
 CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd"]
 
 
-def cpu_baseline(wl, model, mc, seconds_budget=30.0):
-    """The CPU oracle (torch-CPU fp32 restatement of the same step) on a bounded sample."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, model, mc, seconds_budget=25.0):
+    """The CPU oracle (torch-CPU fp32 restatement of the same step) on a bounded sample: a first
+    step on 4 utterances sizes the batch that fits the time budget (the whole batch when it does)."""
     from oracle import model as om
-    from tests.modelutil import oracle_cfg
     V = wl["vocab"] + 1
-    cores = os.cpu_count() or 1
-    cores = min(cores, 16)
-    torch.set_num_threads(cores)
-    Bs = min(wl["B"], 4)
-    ocfg = oracle_cfg(mc, V, wl["feat"])
-    p = {k: v.clone() for k, v in model.store.state_dict().items()}
-    for k, v in p.items():
-        if not k.endswith(om.TRAINABLE_SKIP):
-            v.requires_grad_(True)
-    s = om.make_samples(Bs, wl["T"], wl["feat"], V, wl["U"], seed=1, full_length=True)
-    st = {"iterations": 0, "m": {}, "v": {}}
-    times = []
-    t_start = time.time()
-    for i in range(3):
-        t0 = time.time()
-        om.train_step(p, st, s, ocfg, {"clip_norm": wl["clip_norm"]}, dict(wl["opt"]))
-        times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget:
-            break
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    torch.set_num_threads(threads)
+    ocfg = dict(mc["model_config"], num_class=V, feat_dim=wl["feat"], mtl_weight=mc["mtl_weight"])
+    state = model.store.state_dict()
+
+    def run(Bs, steps):
+        p = {k: v.clone() for k, v in state.items()}
+        for k, v in p.items():
+            if not k.endswith(om.TRAINABLE_SKIP):
+                v.requires_grad_(True)
+        smp = om.make_samples(Bs, wl["T"], wl["feat"], V, wl["U"], seed=1, full_length=True)
+        st = {"iterations": 0, "m": {}, "v": {}}
+        times = []
+        for _ in range(steps):
+            t0 = time.time()
+            om.train_step(p, st, smp, ocfg, {"clip_norm": wl["clip_norm"]}, dict(wl["opt"]))
+            times.append(time.time() - t0)
+        return times
+
+    t_all = time.time()
+    probe = min(wl["B"], 4)
+    first = run(probe, 2)
+    per_utt = first[-1] / probe
+    # two more steps of the largest batch (a multiple of the probe) that fits what is left of the budget
+    left = seconds_budget - (time.time() - t_all)
+    Bs = probe
+    for cand in sorted({probe * 2 ** i for i in range(1, 8)} | {wl["B"]}):
+        if cand <= wl["B"] and per_utt * cand * 2 <= left:
+            Bs = max(Bs, cand)
+    times = run(Bs, 2) if Bs > probe else first
     t = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": Bs * wl["T"] * FRAME_SHIFT_S / t, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-            "sample": "%d of %d utterances per step (T=%d), %d steps, fastest after warm-up; torch-CPU fp32 "
-                      "oracle of the same training step" % (Bs, wl["B"], wl["T"], len(times))}
+    return {"value": Bs * wl["T"] * FRAME_SHIFT_S / t, "unit": "audio-sec/sec", "cores": threads, "kind": "port",
+            "host_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
+            "sample": "%d of %d utterances per step (T=%d), 2 steps, the second one timed; torch-CPU fp32 "
+                      "oracle of the same training step on %d threads" % (Bs, wl["B"], wl["T"], threads)}
 
 
 def pmc_traffic(workload, family):
     """HBM bytes per launch of a kernel family from the committed PMC passes (FETCH_SIZE doubled as
     the gfx950 counter reports half of a wide streaming read, plus WRITE_SIZE; made by
     scripts/pmc_traffic.py from two ``rocprofv3 --pmc`` runs of this benchmark), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -260,12 +323,12 @@ def main():
         sys.stderr.write("[bench rank %d/%d] %s\n" % (rank, world, msg))
         sys.stderr.flush()
 
-    from oracle import model as om      # synthetic batch generator only (inputs, not the measured path)
+    from athena_amd.data import make_samples
     model, opt, solver, mc = build(wl, args.precision, seed=1)
     if args.no_graph:
         solver.hparams.enable_tf_function = False
     V = wl["vocab"] + 1
-    samples = om.make_samples(wl["B"], wl["T"], wl["feat"], V, wl["U"], seed=1 + rank, full_length=True)
+    samples = make_samples(wl["B"], wl["T"], wl["feat"], V, wl["U"], seed=1 + rank, full_length=True)
     ds = model.prepare_samples(samples)          # resident in HBM before the timed region
     if dist.is_initialized():
         solver.broadcast_variables()
@@ -296,18 +359,31 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.detach())
 
-    # per-kernel timing pass (eager, HIP events around the C-ABI entry points), rank 0 only
-    roof = ctc_roof = attn_roof = None
-    if rank == 0:
+    # per-kernel timing pass (eager, HIP events around the C-ABI entry points).  Only the one-GPU run
+    # carries it: with several ranks the others would sit in a collective for its whole length.
+    roof = ctc_roof = attn_roof = parts = None
+    if rank == 0 and world == 1:
         was = solver.hparams.enable_tf_function
         solver.hparams.enable_tf_function = False
-        # this pass runs on rank 0 alone: the gradient exchange is switched off for it (the other
-        # ranks are not taking steps any more and would never join the collective)
         was_dp = (solver.world_size, getattr(solver, "_force_exchange", False))
         solver.world_size, solver._force_exchange = 1, False
+        Vp = (V + 7) // 8 * 8
+        from athena_amd import _lib
+
+        def classify(name, a):
+            if name in ATTN_ENTRIES:
+                return "attention"
+            if name in CTC_ENTRIES:
+                return "ctc"
+            if name.startswith("athena_conv3x3s2"):
+                return "conv2"
+            if name == "athena_gemm":
+                d = a[0]._obj if hasattr(a[0], "_obj") else a[0]
+                return "vocab" if any(x in (V, Vp) for x in (d.M, d.N, d.K)) else "layer_gemm"
+            return "layer_gemm"                     # grouped launches: q/k/v projections, a layer's weight gradients
         nrep = 3
         solver.train_step(ds)
-        with KernelTimer(GEMM_ENTRIES + ATTN_ENTRIES + CTC_ENTRIES) as kt:
+        with KernelTimer(GEMM_ENTRIES + ATTN_ENTRIES + CTC_ENTRIES, classify) as kt:
             kt.calibrate()
             for _ in range(nrep):
                 gpu_plug(40.0)
@@ -315,23 +391,34 @@ def main():
                 torch.cuda.synchronize()
         solver.hparams.enable_tf_function = was
         solver.world_size, solver._force_exchange = was_dp
-        g_ms, g_calls = kt.total_ms(GEMM_ENTRIES)
-        flops = gemm_flops_per_step(wl) * nrep
-        ach = flops / (g_ms * 1e-3) / 1e12
+        fl = gemm_flops_parts(wl)
+        g_ms, g_calls = kt.total_ms(["conv2", "layer_gemm", "vocab"])
+        flops = sum(fl.values())
+        ach = flops * nrep / (g_ms * 1e-3) / 1e12
         roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel (+ splitk_reduce): every Dense and "
                           "implicit-GEMM Conv2D launch of a step",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "gemm"),
                 "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep,
-                "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_floor_us": 1e3 * kt.floor_ms,
-                "flops_per_step": gemm_flops_per_step(wl)}
-        a_ms, a_calls = kt.total_ms(ATTN_ENTRIES)
-        aa = attention_flops_per_step(wl) * nrep / (a_ms * 1e-3) / 1e12
-        attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_dq/dkv_mfma_kernel (+ delta)", "bound": "mfma",
-                     "achieved": aa, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": aa / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms_per_step": a_ms / nrep,
-                     "launches_per_step": a_calls // nrep}
-        c_ms, _ = kt.total_ms(CTC_ENTRIES)
+                "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_pair_cost_us": 1e3 * kt.floor_ms,
+                "flops_per_step": flops}
+        parts = {}
+        for key in ("conv2", "layer_gemm", "vocab"):
+            ms, calls = kt.total_ms([key])
+            if calls == 0:
+                continue
+            a_ = fl[key] * nrep / (ms * 1e-3) / 1e12
+            parts[key] = {"bound": "mfma", "achieved": a_, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": a_ / MFMA_BF16_PEAK_TFLOPS, "ms_per_step": ms / nrep,
+                          "launches_per_step": calls // nrep, "flops_per_step": fl[key]}
+        a_ms, a_calls = kt.total_ms(["attention"])
+        if a_calls:
+            aa = attention_flops_per_step(wl) * nrep / (a_ms * 1e-3) / 1e12
+            attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_*_mfma_kernel", "bound": "mfma",
+                         "achieved": aa, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": aa / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms_per_step": a_ms / nrep,
+                         "launches_per_step": a_calls // nrep}
+        c_ms, _ = kt.total_ms(["ctc"])
         cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
         ctc_roof = {"kernel": "ctc_fwd_kernel (row logsumexp + lattice) + ctc_finish + ctc_grad", "bound": "hbm",
                     "achieved": cb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS,
@@ -341,22 +428,27 @@ def main():
     if rank == 0:
         audio_s = wl["B"] * wl["T"] * FRAME_SHIFT_S * world * args.steps
         out = {
-            "metric": "audio-sec/sec fwd+bwd, Transformer-CTC AISHELL b32 T=1000",
+            "metric": "audio-sec/sec fwd+bwd, Transformer-CTC AISHELL b32 T=1000" if args.workload == "aishell_b32_t1000"
+            else "audio-sec/sec fwd+bwd, Transformer-CTC workload %s" % args.workload,
             "value": audio_s / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": args.workload, "per_gpu_batch": wl["B"], "global_batch": wl["B"] * world,
                        "frames": wl["T"], "fbank_dim": wl["feat"], "classes": V, "parallelism": "dp%d" % world,
-                       "hip_graph": bool(solver.hparams.enable_tf_function), "dropout": wl["rate"]},
+                       "hip_graph": bool(solver.hparams.enable_tf_function), "dropout": wl["rate"],
+                       "encoder_layers": wl["enc"], "decoder_layers": wl["dec"],
+                       "mtl_weight": wl.get("mtl_weight", 0.5)},
             "final_loss": final_loss,
-            "roofline": roof, "roofline_attention": attn_roof, "roofline_ctc": ctc_roof,
+            # the accuracy metrics are queued on the device every step and scored on the host (greedy
+            # collapse + edit distance) only when read, which the timed loop never does
+            "metrics_scored_in_timed_region": False,
+            "roofline": roof, "roofline_parts": parts, "roofline_attention": attn_roof, "roofline_ctc": ctc_roof,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, model, mc)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
-        log("waiting for the other ranks")
-        barrier()          # the other ranks wait here for rank 0's timing pass before the group goes away
+        barrier()
         dist.destroy_process_group()
 
 

@@ -2,28 +2,7 @@
 import torch
 
 
-class DataDescriptions:
-    """The part of a dataset builder the models read (reference
-    athena/data/datasets/speech_recognition.py:134-206): num_class, sample_shape, hparams."""
-
-    class _HP:
-        def __init__(self):
-            self.text_config = {"type": "vocab", "model": None}
-            self.words = None
-
-    def __init__(self, num_class, feat_dim, in_channels=1):
-        self.num_class = num_class
-        self.sample_shape = {"input": (None, feat_dim, in_channels), "input_length": (), "output": (None,),
-                             "output_length": ()}
-        self.hparams = self._HP()
-
-
-def model_config(d_model, num_filters, heads, enc, dec, dff, rate=0.0, mtl_weight=0.5, ls=0.0):
-    return {"model": "speech_transformer",
-            "model_config": {"return_encoder_output": True, "num_filters": num_filters, "d_model": d_model,
-                             "num_heads": heads, "num_encoder_layers": enc, "num_decoder_layers": dec, "dff": dff,
-                             "rate": rate, "label_smoothing_rate": ls},
-            "mtl_weight": mtl_weight}
+from athena_amd.data.synthetic import DataDescriptions, model_config  # noqa: F401,E402
 
 
 def oracle_cfg(mc, num_class_plus1, feat_dim):

@@ -242,7 +242,11 @@ def _attn_ref(q, k, v, key_mask, causal, scale):
                                                 (2, 4, 33, 70, 64, False), (1, 8, 130, 130, 32, False),
                                                 (2, 2, 5, 5, 16, True), (2, 2, 250, 250, 64, False),
                                                 (1, 2, 33, 250, 64, False), (1, 1, 70, 70, 128, True),
-                                                (2, 4, 200, 200, 64, True), (1, 2, 64, 128, 32, False)])
+                                                (2, 4, 200, 200, 64, True), (1, 2, 64, 128, 32, False),
+                                                # LibriSpeech-long: 750 frames after the front end, 8 heads of 64;
+                                                # decoder cross-attention of 151 label positions over them
+                                                (2, 8, 750, 750, 64, False), (2, 8, 151, 750, 64, False),
+                                                (1, 8, 151, 151, 64, True)])
 def test_mha(ops, cd, B, h, Tq, Tk, dk, causal):
     g = torch.Generator().manual_seed(B * 100 + Tq + dk)
     d = h * dk

@@ -44,10 +44,13 @@ from tests.modelutil import model_config  # noqa: E402
 TIMIT_DIMS = dict(vocab=49, feat=40, mc=model_config(256, 256, 8, 9, 3, 1024, ls=0.1), B=2, T=96, U=7)
 AISHELL_DIMS = dict(vocab=4232, feat=80, mc=model_config(256, 256, 4, 3, 2, 1024, ls=0.1), B=2, T=120, U=9)
 LIBRI_DIMS = dict(vocab=5000, feat=80, mc=model_config(512, 512, 8, 2, 1, 2048, mtl_weight=0.3), B=1, T=200, U=12)
+# no decoder layers and the loss is the CTC term alone (mtl_weight 0): the attention branch still produces its
+# logits and its accuracy, as in the reference (mtl_seq2seq.py:86-97), with zero gradient
+ENCODER_ONLY = dict(vocab=60, feat=20, mc=model_config(64, 32, 2, 3, 0, 128, mtl_weight=0.0), B=3, T=90, U=8)
 
 
-@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS],
-                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims"])
+@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS, ENCODER_ONLY],
+                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims", "encoder-only"])
 def test_fp32_forward_loss_backward(case):
     model, samples, ocfg = build(case, "fp32")
     p = oracle_params(model)
@@ -242,8 +245,8 @@ def test_data_parallel_step_structure_on_one_gpu():
         assert worst <= 1e-4, (mode, worst)
 
 
-@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS],
-                         ids=["tiny", "small", "timit-dims", "aishell-dims"])
+@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS, ENCODER_ONLY],
+                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims", "encoder-only"])
 def test_bf16_logits_close_to_fp32_oracle(case):
     model, samples, ocfg = build(case, "bf16")
     p = oracle_params(model, torch.float32)
