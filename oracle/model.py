@@ -238,14 +238,41 @@ def forward(p, samples, cfg, training=True, bn_stats_out=None):
 # ----------------------------------------------------------------------------
 # losses (reference athena/loss.py:24-80)
 # ----------------------------------------------------------------------------
+class _TfDenseCtc(torch.autograd.Function):
+    """Per-sample loss of oracle.ctc.ctc_loss_tf_dense (TensorFlow's dense branch with its finite
+    log(1e-307) "log zero") with that function's own gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, label_length, logit_length):
+        from . import ctc as octc
+        loss, grad = octc.ctc_loss_tf_dense(logits.detach().double().numpy(), labels.numpy(), label_length.numpy(),
+                                            logit_length.numpy(), blank_index=-1)
+        ctx.grad = torch.from_numpy(grad).to(logits.dtype)
+        return torch.from_numpy(loss).to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.grad * g[:, None, None], None, None, None
+
+
 def ctc_loss_mean(ctc_logits, samples, logit_length):
     """CTCLoss.__call__ (loss.py:35-46): blank = V-1, mean over the batch.  torch's CPU
     ctc_loss is used as the differentiable implementation; tests tie it to
-    oracle.ctc (TF-dense restatement, textbook recursion, brute force)."""
+    oracle.ctc (TF-dense restatement, textbook recursion, brute force).  Samples whose labels do
+    not fit their frames, where torch returns inf and TensorFlow's dense branch a finite value of
+    about 7e2, take the TF-dense restatement instead."""
     V = ctc_logits.shape[-1]
     lp = F.log_softmax(ctc_logits, dim=-1).transpose(0, 1)
     per = F.ctc_loss(lp, samples["output"].long(), logit_length.long(), samples["output_length"].long(),
-                     blank=V - 1, reduction="none", zero_infinity=False)
+                     blank=V - 1, reduction="none", zero_infinity=True)
+    probe = F.ctc_loss(lp.detach(), samples["output"].long(), logit_length.long(), samples["output_length"].long(),
+                       blank=V - 1, reduction="none", zero_infinity=False)
+    bad = torch.isinf(probe) | (logit_length <= 0)
+    if bool(bad.any()):
+        idx = torch.nonzero(bad).flatten()
+        tf = _TfDenseCtc.apply(ctc_logits[idx], samples["output"][idx], samples["output_length"][idx].long(),
+                               logit_length[idx].long())
+        per = per.index_put((idx,), tf)
     return per.mean()
 
 
