@@ -1,12 +1,12 @@
-"""Training entry point: JSON configuration -> model, optimizer, checkpoints, epoch loop
-(mirror of the reference's athena/main.py:37-198 for the models this package builds).
+"""Training entry point: JSON configuration -> model, optimizer, checkpoints, epoch loop.
 
     python -m athena_amd.main config.json
 
-The top-level keys and their defaults are the reference's (main.py:58-82); unknown keys raise
-``KeyError`` as there.  ``dataset_builder`` names come from ``SUPPORTED_DATASET_BUILDER``: this
-package ships the synthetic builder only, the corpus-reading builders of the reference are named so
-that a configuration using them fails with a clear message instead of a missing key.
+Same top-level keys, defaults and name tables as the reference's entry point (athena/main.py:26-82;
+unknown keys raise ``KeyError``), and the same four callables -- ``parse_config``,
+``parse_jsonfile``, ``build_model_from_jsonfile``, ``train`` (main.py:84-185).  The work itself is
+organised around two objects: ``Setup`` (everything a configuration builds once) and ``EpochRunner``
+(the train / evaluate / checkpoint cycle of one process).
 """
 import json
 import logging
@@ -75,81 +75,121 @@ DEFAULT_CONFIGS = {
 
 
 def parse_config(config):
-    """dict -> hparams (main.py:84-88)"""
-    p = register_and_parse_hparams(DEFAULT_CONFIGS, config, cls="main")
-    logging.info("hparams: %s", p)
-    return p
+    """dict of top-level keys -> hparams (main.py:84-88)."""
+    hp = register_and_parse_hparams(DEFAULT_CONFIGS, config, cls="main")
+    logging.info("hparams: %s", hp)
+    return hp
 
 
 def parse_jsonfile(jsonfile):
-    """json file -> hparams (main.py:90-98)"""
-    with open(jsonfile) as file:
-        config = json.load(file)
-    return parse_config(config)
+    """JSON file -> hparams (main.py:90-98)."""
+    with open(jsonfile) as f:
+        return parse_config(json.load(f))
+
+
+def _lookup(table, name, what):
+    if name not in table:
+        raise NotImplementedError("%s %r is not built by this package (built: %s)" % (what, name, ", ".join(sorted(table))))
+    return table[name]
+
+
+class Setup:
+    """What one configuration file builds: hparams, model, optimizer, checkpoint manager.
+
+    Constructing the checkpoint manager restores the newest snapshot of ``ckpt`` when there is one,
+    so ``epochs_done`` is where a run resumes."""
+
+    def __init__(self, jsonfile, pre_run=True):
+        self.hparams = hp = parse_jsonfile(jsonfile)
+        model_cls = _lookup(SUPPORTED_MODEL, hp.model, "model")
+        if hp.trainset_config is None and hp.num_classes is None:
+            raise ValueError("trainset_config and num_classes can not both be null")
+        self.train_data = self.dataset(hp.dataset_builder, hp.trainset_config)
+        self.model = model_cls(data_descriptions=self.train_data, config=hp.model_config)
+        self.optimizer = _lookup(SUPPORTED_OPTIMIZER, hp.optimizer, "optimizer")(hp.optimizer_config)
+        self.optimizer.attach(self.model.store)
+        self.checkpointer = Checkpoint(checkpoint_directory=hp.ckpt, model=self.model, optimizer=self.optimizer)
+        if pre_run or hp.pretrained_model is not None:
+            self._trial_step()
+
+    @staticmethod
+    def dataset(builder_name, config):
+        return _lookup(SUPPORTED_DATASET_BUILDER, builder_name, "dataset builder")(config)
+
+    def _trial_step(self):
+        # The reference evaluates one batch here so that Keras creates the variables (main.py:119-127).
+        # The variables of this package exist from construction; the step stays as an early check
+        # that the configuration runs at all.
+        solver = BaseSolver(self.model, self.optimizer, sample_signature=self.train_data.sample_signature)
+        first = next(iter(self.train_data.as_dataset(self.hparams.batch_size)))
+        solver.evaluate_step(self.model.prepare_samples(first))
+        self.model.reset_metrics()
+
+    @property
+    def epochs_done(self):
+        return int(self.checkpointer.save_counter)
+
+    def as_tuple(self):
+        return self.hparams, self.model, self.optimizer, self.checkpointer
 
 
 def build_model_from_jsonfile(jsonfile, pre_run=True):
-    """Model, optimizer and checkpoint manager of a configuration; restores the latest snapshot of
-    the checkpoint directory if there is one (main.py:100-128)."""
-    p = parse_jsonfile(jsonfile)
-    if p.model not in SUPPORTED_MODEL:
-        raise NotImplementedError("model %r is not built by this package (built: %s)" %
-                                  (p.model, ", ".join(sorted(SUPPORTED_MODEL))))
-    dataset_builder = SUPPORTED_DATASET_BUILDER[p.dataset_builder](p.trainset_config)
-    if p.trainset_config is None and p.num_classes is None:
-        raise ValueError("trainset_config and num_classes can not both be null")
-    model = SUPPORTED_MODEL[p.model](data_descriptions=dataset_builder, config=p.model_config)
-    optimizer = SUPPORTED_OPTIMIZER[p.optimizer](p.optimizer_config)
-    optimizer.attach(model.store)
-    checkpointer = Checkpoint(checkpoint_directory=p.ckpt, model=model, optimizer=optimizer)
-    if pre_run or p.pretrained_model is not None:
-        # the reference runs one evaluation step here to make Keras create the variables; here the
-        # variables exist already and the step only checks that the configuration runs
-        solver = BaseSolver(model, optimizer, sample_signature=dataset_builder.sample_signature)
-        dataset = dataset_builder.as_dataset(p.batch_size)
-        solver.evaluate_step(model.prepare_samples(next(iter(dataset))))
-        model.reset_metrics()
-    return p, model, optimizer, checkpointer
+    """(hparams, model, optimizer, checkpointer) of a configuration file (main.py:100-128)."""
+    return Setup(jsonfile, pre_run).as_tuple()
+
+
+class EpochRunner:
+    """The epoch cycle of one process (rank ``rank`` of ``rank_size``): batches of the process's
+    shard -> ``solver.train``; the whole dev set -> ``solver.evaluate``; rank 0 saves a checkpoint
+    with the dev loss (main.py:168-185)."""
+
+    def __init__(self, setup, solver_cls, rank_size=1, rank=0):
+        hp = setup.hparams
+        self.setup, self.rank = setup, rank
+        self.chief = rank == 0
+        self.trainset = Setup.dataset(hp.dataset_builder, hp.trainset_config)
+        self.trainset.compute_cmvn_if_necessary(self.chief)
+        self.trainset.shard(rank_size, rank)
+        self.devset = Setup.dataset(hp.dev_dataset_builder or hp.dataset_builder, hp.devset_config)
+        self.solver = solver_cls(setup.model, setup.optimizer, sample_signature=self.trainset.sample_signature,
+                                 eval_sample_signature=self.devset.sample_signature, config=hp.solver_config)
+
+    def _say(self, fmt, *args):
+        if self.chief:
+            logging.info(fmt, *args)
+
+    def run_epoch(self, epoch):
+        hp = self.setup.hparams
+        self._say(">>>>> start training in epoch %d", epoch)
+        if epoch >= hp.sorta_epoch:                       # the first epochs go through the set sorted by length
+            self.trainset.batch_wise_shuffle(hp.batch_size)
+        self.solver.train(self.trainset.as_dataset(hp.batch_size, hp.num_data_threads))
+        self._say(">>>>> start evaluate in epoch %d", epoch)
+        result = self.solver.evaluate(self.devset.as_dataset(hp.batch_size, hp.num_data_threads), epoch)
+        if self.chief:
+            self.setup.checkpointer(*result)
+        return result
+
+    def run(self, first_epoch):
+        result = (0.0, {})
+        for epoch in range(first_epoch, self.setup.hparams.num_epochs):
+            result = self.run_epoch(epoch)
+        return result
 
 
 def train(jsonfile, Solver, rank_size=1, rank=0):
-    """The epoch loop: train, evaluate, checkpoint (main.py:131-185)."""
-    p, model, optimizer, checkpointer = build_model_from_jsonfile(jsonfile)
-    epoch = int(checkpointer.save_counter)
-    if p.pretrained_model is not None and epoch == 0:
-        p2, pretrained_model, _, _ = build_model_from_jsonfile(p.pretrained_model)
-        model.restore_from_pretrained_model(pretrained_model, p2.model)
-    if p.teacher_model is not None:
+    """Train ``jsonfile`` from the epoch its checkpoint directory stands at; returns the last
+    evaluation's (loss, metrics) (main.py:131-185)."""
+    setup = Setup(jsonfile)
+    hp = setup.hparams
+    if hp.teacher_model is not None:
         raise NotImplementedError("teacher_model (knowledge distillation of the TTS models) is not built")
+    if hp.pretrained_model is not None and setup.epochs_done == 0:
+        donor = Setup(hp.pretrained_model)
+        setup.model.restore_from_pretrained_model(donor.model, donor.hparams.model)
     if rank == 0:
-        set_default_summary_writer(p.summary_dir)
-
-    trainset_builder = SUPPORTED_DATASET_BUILDER[p.dataset_builder](p.trainset_config)
-    trainset_builder.compute_cmvn_if_necessary(rank == 0)
-    trainset_builder.shard(rank_size, rank)
-
-    devset_builder = p.dev_dataset_builder if p.dev_dataset_builder is not None else p.dataset_builder
-    devset_builder = SUPPORTED_DATASET_BUILDER[devset_builder](p.devset_config)
-
-    solver = Solver(model, optimizer, sample_signature=trainset_builder.sample_signature,
-                    eval_sample_signature=devset_builder.sample_signature, config=p.solver_config)
-    loss, metrics = 0.0, {}
-    while epoch < p.num_epochs:
-        if rank == 0:
-            logging.info(">>>>> start training in epoch %d", epoch)
-        if epoch >= p.sorta_epoch:
-            trainset_builder.batch_wise_shuffle(p.batch_size)
-        solver.train(trainset_builder.as_dataset(p.batch_size, p.num_data_threads))
-
-        if rank == 0:
-            logging.info(">>>>> start evaluate in epoch %d", epoch)
-        devset = devset_builder.as_dataset(p.batch_size, p.num_data_threads)
-        loss, metrics = solver.evaluate(devset, epoch)
-
-        if rank == 0:
-            checkpointer(loss, metrics)
-        epoch = epoch + 1
-    return loss, metrics
+        set_default_summary_writer(hp.summary_dir)
+    return EpochRunner(setup, Solver, rank_size, rank).run(setup.epochs_done)
 
 
 def main(argv=None):
@@ -159,8 +199,7 @@ def main(argv=None):
         logging.warning("Usage: python %s config_json_file", argv[0])
         return 1
     torch.manual_seed(1)                    # tf.random.set_seed(1) (main.py:193)
-    p = parse_jsonfile(argv[1])
-    BaseSolver.initialize_devices(p.solver_gpu)
+    BaseSolver.initialize_devices(parse_jsonfile(argv[1]).solver_gpu)
     train(argv[1], BaseSolver, 1, 0)
     return 0
 

@@ -1,88 +1,94 @@
-"""Log-line formatter for training / evaluation (mirror of the reference's
-athena/utils/metric_check.py:22-120; the tf.summary scalars are replaced by an optional
-tab-separated ``scalars.tsv`` in the summary directory)."""
+"""Log lines for training / evaluation.
+
+The line format is the contract with the reference (athena/utils/metric_check.py:51-120):
+tab-separated ``name: value`` fields -- ``global_steps``, ``learning_rate``, ``loss``, one field per
+named loss and per metric, and ``sec/iter`` from the second report on (training);
+``epoch`` (when one is given), ``loss`` and the metrics (evaluation).  In place of the reference's
+``tf.summary.scalar`` events every reported scalar is appended to ``scalars.tsv`` in the summary
+directory (``step <tab> tag <tab> value``).
+"""
 import os
 import time
 
-_SUMMARY_DIR = None
+
+class _ScalarLog:
+    """Append-only ``scalars.tsv`` in the summary directory; inactive until a directory is set."""
+    directory = None
+
+    @classmethod
+    def open(cls, directory):
+        os.makedirs(directory, exist_ok=True)
+        cls.directory = directory
+
+    @classmethod
+    def write(cls, step, rows):
+        if cls.directory is None or not rows:
+            return
+        with open(os.path.join(cls.directory, "scalars.tsv"), "a") as f:
+            f.writelines("%d\t%s\t%.8g\n" % (step, tag, val) for tag, val in rows)
 
 
 def set_default_summary_writer(summary_directory=None):
-    """reference athena/utils/misc.py:188-193"""
-    global _SUMMARY_DIR
-    if summary_directory is None:
-        summary_directory = os.path.join(os.path.expanduser("~"), ".athena", "event")
-    os.makedirs(summary_directory, exist_ok=True)
-    _SUMMARY_DIR = summary_directory
+    """Where the scalars go; default ~/.athena/event (reference athena/utils/misc.py:188-193)."""
+    _ScalarLog.open(summary_directory or os.path.join(os.path.expanduser("~"), ".athena", "event"))
 
 
-def _scalar(tag, value, step):
-    if _SUMMARY_DIR is None:
-        return
-    with open(os.path.join(_SUMMARY_DIR, "scalars.tsv"), "a") as f:
-        if hasattr(value, "detach"):
-            value = value.detach()
-        f.write("%d\t%s\t%.8g\n" % (step, tag, float(value)))
+def _num(x):
+    return float(x.detach()) if hasattr(x, "detach") else float(x)
+
+
+def _loss_fields(loss):
+    """[("loss", total)] followed by the named parts of a dict-valued loss."""
+    if isinstance(loss, dict):
+        parts = [(name, _num(v)) for name, v in loss.items()]
+        return [("loss", sum(v for _, v in parts))] + parts
+    return [("loss", _num(loss))]
 
 
 class MetricChecker:
-    """Formats ``global_steps / learning_rate / loss / metrics / sec/iter`` lines."""
+    """Callable that turns (loss, metrics) into the report line and logs the scalars.
+
+    ``checker(loss, metrics)`` reports a training step; ``checker(loss, metrics, epoch)`` an
+    evaluation (``epoch`` < -1: a running report inside an evaluation, without epoch and scalars)."""
 
     def __init__(self, optimizer):
         self.optimizer = optimizer
-        self.time_last_call = time.time()
-        self.steps_last_call = 0
+        self._clock = time.time()
+        self._steps_at_clock = 0
 
     def __call__(self, loss, metrics, evaluate_epoch=-1):
         if evaluate_epoch == -1:
             return self.summary_train(loss, metrics)
         return self.summary_evaluate(loss, metrics, evaluate_epoch)
 
+    def _step_and_rate(self):
+        step = int(self.optimizer.iterations)
+        lr = self.optimizer.lr
+        return step, float(lr(step) if callable(lr) else lr)
+
     def summary_train(self, loss, metrics):
-        global_steps = int(self.optimizer.iterations)
-        learning_rate = self.optimizer.lr(global_steps) if callable(self.optimizer.lr) else self.optimizer.lr
-        total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
-        _scalar("total_loss", total_loss, global_steps)
-        if isinstance(loss, dict):
-            for name in loss:
-                _scalar(name, loss[name], global_steps)
-        _scalar("learning_rate", learning_rate, global_steps)
-        reports = ""
-        reports += "global_steps: %d\t" % (global_steps)
-        reports += "learning_rate: %.4e\t" % (learning_rate)
-        reports += "loss: %.4f\t" % (float(total_loss.detach() if hasattr(total_loss, "detach") else total_loss))
-        if isinstance(loss, dict):
-            for name in loss:
-                reports += "%s: %.4f\t" % (name, float(loss[name]))
-        if metrics is not None:
-            for name in metrics:
-                metric = float(metrics[name])
-                _scalar(name, metric, global_steps)
-                reports += "%s: %.4f\t" % (name, metric)
-        right_now = time.time()
-        duration = right_now - self.time_last_call
-        self.time_last_call = right_now
-        if self.steps_last_call != 0:
-            sec_per_iter = duration / float(global_steps - self.steps_last_call)
-            reports += "sec/iter: %.4f" % (sec_per_iter)
-        self.steps_last_call = global_steps
-        return reports
+        step, lr = self._step_and_rate()
+        losses = _loss_fields(loss)
+        scores = [(name, float(v)) for name, v in (metrics or {}).items()]
+        _ScalarLog.write(step, [("total_loss", losses[0][1])] + losses[1:] + [("learning_rate", lr)] + scores)
+        line = ["global_steps: %d" % step, "learning_rate: %.4e" % lr]
+        line += ["%s: %.4f" % kv for kv in losses + scores]
+        now = time.time()
+        elapsed, self._clock = now - self._clock, now
+        tail = ""
+        if self._steps_at_clock:
+            tail = "sec/iter: %.4f" % (elapsed / float(step - self._steps_at_clock))
+        self._steps_at_clock = step
+        return "\t".join(line) + "\t" + tail
 
     def summary_evaluate(self, loss, metrics, epoch=-1):
-        reports = ""
-        global_steps = int(self.optimizer.iterations)
-        total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
+        step, _ = self._step_and_rate()
+        losses = _loss_fields(loss)
+        scores = [(name, float(v)) for name, v in (metrics or {}).items()]
+        line = []
         if epoch >= 0:
-            _scalar("evaluate_total_loss", total_loss, global_steps)
-            reports += "epoch: %d\t" % (epoch)
-        reports += "loss: %.4f\t" % (float(total_loss.detach() if hasattr(total_loss, "detach") else total_loss))
-        if isinstance(loss, dict):
-            for name in loss:
-                reports += "%s: %.4f\t" % (name, float(loss[name]))
-        if metrics is not None:
-            for name in metrics:
-                metric = float(metrics[name])
-                if epoch >= 0:
-                    _scalar("evaluate_" + name, metric, global_steps)
-                reports += "%s: %.4f\t" % (name, metric)
-        return reports
+            _ScalarLog.write(step, [("evaluate_total_loss", losses[0][1])] +
+                             [("evaluate_" + name, v) for name, v in losses[1:] + scores])
+            line.append("epoch: %d" % epoch)
+        line += ["%s: %.4f" % kv for kv in losses + scores]
+        return "\t".join(line) + "\t"

@@ -350,3 +350,34 @@ def test_synthetic_dataset_builder_batches_shards_and_shuffles():
     assert {tuple(b.order[i:i + 8]) for i in range(0, 32, 8)} == {tuple(before[i:i + 8]) for i in range(0, 32, 8)}
     with pytest.raises(KeyError):
         Builder({"unknown": 1})
+
+
+def test_metric_checker_lines_follow_the_reference_format(tmp_path):
+    """Tab-separated ``name: value`` fields in the order of reference athena/utils/metric_check.py:71-93
+    and :99-120; ``sec/iter`` only from the second training report on; scalars land in scalars.tsv."""
+    import re
+    from athena_amd.utils import metric_check as mcheck
+
+    class Opt:
+        iterations = 10
+
+        @staticmethod
+        def lr(step):
+            return 1.25e-4
+
+    mcheck.set_default_summary_writer(str(tmp_path))
+    chk = mcheck.MetricChecker(Opt())
+    first = chk(2.5, {"Accuracy": 0.75, "CTCAccuracy": 0.5})
+    assert first == "global_steps: 10\tlearning_rate: 1.2500e-04\tloss: 2.5000\tAccuracy: 0.7500\tCTCAccuracy: 0.5000\t"
+    Opt.iterations = 20
+    second = chk({"ce": 1.0, "ctc": 2.0}, None)
+    assert re.fullmatch(r"global_steps: 20\tlearning_rate: 1.2500e-04\tloss: 3.0000\tce: 1.0000\tctc: 2.0000\t"
+                        r"sec/iter: \d+\.\d{4}", second), second
+    assert chk(1.5, {"Accuracy": 0.9}, evaluate_epoch=3) == "epoch: 3\tloss: 1.5000\tAccuracy: 0.9000\t"
+    assert chk(1.5, {"Accuracy": 0.9}, evaluate_epoch=-2) == "loss: 1.5000\tAccuracy: 0.9000\t"
+    rows = [line.split("\t") for line in (tmp_path / "scalars.tsv").read_text().strip().split("\n")]
+    tags = [r[1] for r in rows]
+    assert tags == ["total_loss", "learning_rate", "Accuracy", "CTCAccuracy", "total_loss", "ce", "ctc",
+                    "learning_rate", "evaluate_total_loss", "evaluate_Accuracy"]
+    assert rows[0][0] == "10" and rows[-1][0] == "20"
+    mcheck._ScalarLog.directory = None

@@ -288,11 +288,14 @@ def test_bf16_logits_close_to_fp32_oracle(case):
           (ea, ec, float(att_ref.abs().max()), float(ctc_ref.abs().max())))
     # stated tolerance for the single worst logit: 4e-2 absolute, or 1.5 % of the largest |logit| where the
     # logits are larger (bf16 keeps 8 significant bits: a logit of 5 is stored to within 2e-2 at best);
-    # the root-mean-square error stays within 1e-2 absolute
+    # the root-mean-square error stays within 1e-2 absolute (0.4 % of the largest |logit| where that is more:
+    # the 50-class TIMIT head has logits up to 5.4)
     assert ea <= max(BF16_LOGIT_TOL, 1.5e-2 * float(att_ref.abs().max())), ea
     assert ec <= max(BF16_LOGIT_TOL, 1.5e-2 * float(ctc_ref.abs().max())), ec
-    assert float((att.float().cpu() - att_ref.detach()).pow(2).mean().sqrt()) <= 1e-2
-    assert float((ctc.float().cpu() - ctc_ref.detach()).pow(2).mean().sqrt()) <= 1e-2
+    rms_a = float((att.float().cpu() - att_ref.detach()).pow(2).mean().sqrt())
+    rms_c = float((ctc.float().cpu() - ctc_ref.detach()).pow(2).mean().sqrt())
+    assert rms_a <= max(1e-2, 4e-3 * float(att_ref.abs().max())), rms_a
+    assert rms_c <= max(1e-2, 4e-3 * float(ctc_ref.abs().max())), rms_c
     loss, _ = model.get_loss((att, ctc), ds, training=True)
     loss_ref = om.get_loss(att_ref, ctc_ref, samples, ocfg)[0]
     assert_close(loss, loss_ref.detach(), 2e-3, "bf16 loss")
