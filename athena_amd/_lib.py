@@ -30,12 +30,23 @@ class GemmDesc(Structure):
     ]
 
 
+class WgradItem(Structure):
+    """Mirror of ``athena_wgrad_item``."""
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bsum", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32),
+        ("first_tile", c_int32), ("tiles_m", c_int32),
+    ]
+
+
 class AdamCfg(Structure):
     """Mirror of ``athena_adam_cfg``."""
     _fields_ = [
         ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("clip_norm", c_float),
         ("d_model", c_float), ("warmup_steps", c_float), ("k", c_float), ("decay_steps", c_float),
         ("decay_rate", c_float), ("grad_scale", c_float),
+        ("schedule", c_float), ("initial_lr", c_float), ("start_decay_steps", c_float), ("final_lr", c_float),
     ]
 
 
@@ -46,6 +57,8 @@ _SIGNATURES = {
     "athena_abi_version": (c_int, []),
     "athena_gemm": (c_int, [POINTER(GemmDesc), _S]),
     "athena_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _S]),
+    "athena_gemm_wgrad_plan": (c_int, [POINTER(WgradItem), c_int, POINTER(c_int)]),
+    "athena_gemm_wgrad_table": (c_int, [_P, c_int, c_int, _S]),
     "athena_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "athena_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,

@@ -5,7 +5,7 @@ here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../lib"
 mkdir -p "$out" "$here/.obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-inline-asm"
 pids=()
 for f in gemm norm attention loss optim misc frontconv; do
   src="$here/$f.hip"; obj="$here/.obj/$f.o"

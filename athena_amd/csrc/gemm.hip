@@ -1,5 +1,6 @@
 // Dense-layer and Conv2D entry points on top of the shared GEMM cores.
-#include "gemm_core.h"
+#include "gemm_big.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -12,7 +13,18 @@ void athena_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* athena_last_error(void) { return g_err; }
-extern "C" int athena_abi_version(void) { return 4; }
+
+// ATHENA_GEMM_BIG: 0 keeps every product on the 128x128 / 64x64 cores (for A/B measurements), 2 sends
+// every product the 256x256 core can do to it, whatever its size (for tests); default: by size.
+// Read on every call so that a test can switch it.
+static int big_tiles_mode() {
+    const char* v = getenv("ATHENA_GEMM_BIG");
+    return (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : 1;
+}
+static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
+static bool big_tiles_forced() { return big_tiles_mode() == 2; }
+
+extern "C" int athena_abi_version(void) { return 5; }
 
 static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     memset(&e, 0, sizeof(e));
@@ -122,6 +134,12 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
         rc = gemm_zero_fill_for_atomics(d, p.epi.bsum, (hipStream_t)stream);
         if (rc) return rc;
     }
+    // large plain products ([M,K] x [N,K]^T or [K,M]^T x [K,N], no split) run on the 256x256 core
+    const bool big_layout = (!d->trans_a && d->trans_b) || (d->trans_a && !d->trans_b);
+    if (big_tiles_enabled() && big_layout && split == 1 &&
+        (big_tiles_forced() || (d->M >= 1024 && d->N >= 1024 && d->K >= 512 && gemm_tiles(d->M, d->N, 256) >= 200)) &&
+        gemm_big_ok(p, d->in_dtype, d->trans_a != 0))
+        return launch_gemm_big(p, d->trans_a != 0, d->trans_b != 0, (hipStream_t)stream);
     rc = launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, plan.bt, (hipStream_t)stream);
     if (rc) return rc;
     if (use_ws) {
@@ -313,6 +331,11 @@ extern "C" int athena_conv3x3s2_fwd(const void* in, const void* w, int w_layout,
         hipError_t e = hipMemsetAsync(colstats, 0, sizeof(double) * 2 * Cout, (hipStream_t)stream);
         ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_fwd: memset failed");
     }
+    // tall outputs with at least 129 columns go to the 256x256 core (the weights are then read
+    // through their [Cout][9][Cin] copy as a row image)
+    if (big_tiles_enabled() && w_layout == 1 && ((Cout > 128 && p.M >= 64 * GB_BM) || big_tiles_forced()) &&
+        gemm_big_ok(p, dtype, false))
+        return launch_gemm_big(p, false, true, (hipStream_t)stream);
     return launch_gemm(p, dtype, false, w_layout == 1, gemm_plan(p.M, p.N, 9L * Cin, dtype, 1, false).bt,
                        (hipStream_t)stream);
 }
@@ -376,8 +399,12 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
             }
             p.crow_mode = 1;
             p.cr_Ah = Ah; p.cr_Aw = Aw; p.cr_H = H; p.cr_W = W; p.cr_h0 = h0; p.cr_w0 = w0;
-            rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,
-                             (hipStream_t)stream);
+            if (big_tiles_enabled() && ((Cin > 128 && p.M >= 64 * GB_BM) || big_tiles_forced()) &&
+                gemm_big_ok(p, dtype, false))
+                rc = launch_gemm_big(p, false, true, (hipStream_t)stream);
+            else
+                rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,
+                                 (hipStream_t)stream);
             if (rc) return rc;
         }
     }
@@ -403,13 +430,29 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     // dw[tap][ci][co] = sum_r in(r, tap)[ci] * dout[r][co]: A transposed through the gather, B = dout [K][N]
     // the nine taps are nine independent GEMMs stacked in grid.z; split the long contraction so
     // that taps x splits x output tiles fill the chip
-    const GemmPlan plan = gemm_plan(Cin, Cout, rows, dtype, 9, true);
+    GemmPlan plan = gemm_plan(Cin, Cout, rows, dtype, 9, true);
+    // 256x256 tiles: one workgroup per CU, taps x tiles x splits of about the CU count, every split at
+    // least 8 k-tiles long, and the partial sums must fit the workspace
+    bool big = big_tiles_enabled() && dtype == ATHENA_BF16 &&
+               ((Cin > 128 && Cout > 128 && rows >= 64 * GM_BK) || big_tiles_forced()) && workspace &&
+               athena_aligned16(workspace);
+    if (big) {
+        const long tiles = 9L * ((Cin + GB_BM - 1) / GB_BM) * ((Cout + GB_BN - 1) / GB_BN);
+        long sp = 256 / tiles;
+        const long ktiles = (rows + GM_BK - 1) / GM_BK;
+        if (sp > ktiles / 8) sp = ktiles / 8;
+        if (sp < 2 && big_tiles_forced() && ktiles >= 2) sp = 2;
+        while (sp > 1 && splitk_workspace_bytes(Cin, Cout, (int)sp, 9) > (size_t)workspace_bytes) --sp;
+        if (sp < 2 || splitk_workspace_bytes(Cin, Cout, (int)sp, 9) > (size_t)workspace_bytes) big = false;
+        else plan.split = (int)sp;
+    }
     const int split = plan.split;
+    const int kstep = big ? GB_BK : GM_BK;      // rows of the contraction a core advances per step
     GemmProblem<ConvFwdRows> p;
     memset(&p, 0, sizeof(p));
     p.A = in;
     p.B = dout;
-    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw, GM_BK / Wo, GM_BK % Wo};
+    p.amap = ConvFwdRows{H, W, Cin, Ho, Wo, ph, pw, kstep / Wo, kstep % Wo};
     p.M = Cin;
     p.N = Cout;
     p.nseg = 1;
@@ -434,7 +477,8 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
         hipError_t e = hipMemsetAsync(dw_hwio, 0, sizeof(float) * 9L * Cin * Cout, (hipStream_t)stream);
         ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_conv3x3s2_wgrad: memset failed");
     }
-    rc = launch_gemm(p, dtype, true, false, plan.bt, (hipStream_t)stream);
+    if (big && partial) rc = launch_gemm_big(p, true, false, (hipStream_t)stream);
+    else rc = launch_gemm(p, dtype, true, false, plan.bt, (hipStream_t)stream);
     if (rc) return rc;
     if (partial) {
         const long work = (long)(Cin + 1) * (p.epi.ldp / 4);
@@ -443,5 +487,37 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
                            (float*)nullptr);
         ATHENA_CHECK_LAUNCH("athena_conv3x3s2_wgrad(split-k reduce)");
     }
+    return ATHENA_OK;
+}
+
+// ------------------------------------------------------------------ many weight gradients, one launch
+extern "C" int athena_gemm_wgrad_plan(athena_wgrad_item* items, int count, int* total_tiles) {
+    ATHENA_REQUIRE(items && count > 0 && total_tiles, ATHENA_E_SHAPE, "athena_gemm_wgrad_plan: empty table");
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        athena_wgrad_item& it = items[i];
+        ATHENA_REQUIRE(it.A && it.B && it.C && it.M > 0 && it.N > 0 && it.K > 0, ATHENA_E_SHAPE,
+                       "athena_gemm_wgrad_plan: item %d: null operand or empty shape", i);
+        ATHENA_REQUIRE(it.lda % 8 == 0 && it.ldb % 8 == 0 && it.lda >= (it.M + 7) / 8 * 8 && it.ldb >= (it.N + 7) / 8 * 8 &&
+                           it.ldc >= it.N,
+                       ATHENA_E_ALIGN, "athena_gemm_wgrad_plan: item %d: lda=%d ldb=%d ldc=%d for M=%d N=%d", i, it.lda,
+                       it.ldb, it.ldc, it.M, it.N);
+        ATHENA_REQUIRE(athena_aligned16(it.A) && athena_aligned16(it.B), ATHENA_E_ALIGN,
+                       "athena_gemm_wgrad_plan: item %d: operands must be 16-byte aligned", i);
+        it.first_tile = (int32_t)tiles;
+        it.tiles_m = (it.M + GB_BM - 1) / GB_BM;
+        tiles += (long)it.tiles_m * ((it.N + GB_BN - 1) / GB_BN);
+        ATHENA_REQUIRE(tiles < (1L << 30), ATHENA_E_SHAPE, "athena_gemm_wgrad_plan: too many tiles");
+    }
+    *total_tiles = (int)tiles;
+    return ATHENA_OK;
+}
+
+extern "C" int athena_gemm_wgrad_table(const athena_wgrad_item* table_dev, int count, int total_tiles,
+                                       athena_stream_t stream) {
+    ATHENA_REQUIRE(table_dev && count > 0 && total_tiles > 0, ATHENA_E_SHAPE, "athena_gemm_wgrad_table: empty table");
+    hipLaunchKernelGGL(gemm_big_table_kernel, dim3((unsigned)total_tiles), dim3(GB_THREADS), 0, (hipStream_t)stream,
+                       (const GbItem*)table_dev, count);
+    ATHENA_CHECK_LAUNCH("athena_gemm_wgrad_table");
     return ATHENA_OK;
 }

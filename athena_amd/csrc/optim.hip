@@ -63,7 +63,14 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float arg1 = step > 0 ? rsqrtf(fs) : INFINITY;
     const float arg2 = fs * powf(cfg.warmup_steps, -1.5f);
     const float kk = cfg.k * powf(cfg.decay_rate, floorf(fs / cfg.decay_steps));
-    const float lr = kk * rsqrtf(cfg.d_model) * fminf(arg1, arg2);
+    float lr = kk * rsqrtf(cfg.d_model) * fminf(arg1, arg2);
+    if (cfg.schedule == 1.f) {
+        // exponential decay in whole multiples of decay_steps, from start_decay_steps on
+        const float factor = fs < cfg.start_decay_steps
+                                 ? 1.f
+                                 : powf(cfg.decay_rate, floorf((fs - cfg.start_decay_steps) / cfg.decay_steps));
+        lr = fminf(fmaxf(cfg.initial_lr * factor, cfg.final_lr), cfg.initial_lr);
+    }
     const float t = fs + 1.f;
     const float lr_t = lr * sqrtf(1.f - powf(cfg.beta2, t)) / (1.f - powf(cfg.beta1, t));
     if (lr_out && blockIdx.x == 0 && threadIdx.x == 0) lr_out[0] = lr;

@@ -11,6 +11,7 @@ layer), athena/layers/attention.py:147-171 (multi-head attention),
 athena/models/speech_transformer.py:72-113 (x_net / y_net).
 """
 import math
+import os
 
 import torch
 
@@ -96,10 +97,45 @@ class weight_grad_group:
         return False
 
 
+class _WgradQueue:
+    """Dense weight gradients of a whole backward pass, run as ONE launch at its end.
+
+    A weight gradient x^T dy contracts over all rows of the batch and nothing later in the backward
+    pass depends on it, so in bf16 mode ``lin_bwd_w`` only notes the operands here (which keeps them
+    alive) and an end-of-backward callback of the autograd engine hands the whole list to
+    ``ops.gemm_wgrad_table``: every 256x256 tile of every gradient is one workgroup that runs down its
+    whole contraction -- no K split, no partial sums, one launch instead of one per layer.
+    Outside a backward pass (no engine to call back) the product runs at once."""
+    items = []
+    queued = False
+    enabled = os.environ.get("ATHENA_WGRAD_TABLE", "1") != "0"
+
+    @classmethod
+    def push(cls, item):
+        if not cls.queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+            except RuntimeError:
+                return False
+            cls.queued = True
+        cls.items.append(item)
+        return True
+
+    @classmethod
+    def flush(cls):
+        items, cls.items, cls.queued = cls.items, [], False
+        ops.gemm_wgrad_table(items)
+
+
 def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):
     """kernel.grad = x^T @ dy ; bias.grad = column sums of dy.  ``defer=False`` runs the product now
     even inside a ``weight_grad_group`` -- needed when ``dy`` is about to be overwritten."""
     K, N = dense.in_features, dense.out_features
+    aligned = ldx % 8 == 0 and lddy % 8 == 0 and ldx >= ops.roundup(K, 8) and lddy >= ops.roundup(N, 8) and \
+        x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+    if defer and aligned and _WgradQueue.enabled and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and \
+            _WgradQueue.push((x, dy, M, K, N, ldx, lddy, dense.kernel.grad, dense.bias.grad)):
+        return
     kw = dict(trans_a=True, trans_b=False, lda=ldx, ldb=lddy, ldc=N, split_k=0, b_colsum=dense.bias.grad)
     grp = weight_grad_group._open
     if grp is not None and defer:

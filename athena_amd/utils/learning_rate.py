@@ -86,7 +86,7 @@ class WarmUpAdam:
         h = self.hparams
         return _lib.AdamCfg(self.beta_1, self.beta_2, self.epsilon, float(clip_norm), float(h.d_model),
                             float(h.warmup_steps), float(h.k), float(h.decay_steps), float(h.decay_rate),
-                            float(grad_scale))
+                            float(grad_scale), 0.0, 0.0, 0.0, 0.0)
 
     def apply_gradients(self, clip_norm=0.0, grad_scale=1.0):
         """clip_by_norm per tensor + Adam on the flat buffers, then mark the bf16 shadows stale."""
@@ -105,7 +105,8 @@ class WarmUpAdam:
 
 
 class ExponentialDecayAdam(WarmUpAdam):
-    """learning_rate.py:120-146 (API kept; the fused kernel implements the warm-up schedule only)."""
+    """Adam(beta_1=0.9, beta_2=0.999, epsilon=1e-6) driven by ExponentialDecayLearningRateSchedule
+    (learning_rate.py:120-146): the same fused clip + Adam kernel with the other schedule."""
     default_config = {
         "initial_lr": 0.005,
         "decay_steps": 10000,
@@ -124,5 +125,8 @@ class ExponentialDecayAdam(WarmUpAdam):
         self.store = None
         self._host_iterations = 0
 
-    def apply_gradients(self, clip_norm=0.0, grad_scale=1.0):
-        raise NotImplementedError("expdecay_adam is outside the built training path; use warmup_adam")
+    def _cfg(self, clip_norm, grad_scale):
+        h = self.hparams
+        return _lib.AdamCfg(self.beta_1, self.beta_2, self.epsilon, float(clip_norm), 1.0, 1.0, 1.0,
+                            float(h.decay_steps), float(h.decay_rate), float(grad_scale), 1.0, float(h.initial_lr),
+                            float(h.start_decay_steps), float(h.final_lr))

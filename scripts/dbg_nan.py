@@ -4,7 +4,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from athena_amd import MtlTransformerCtc
 from athena_amd.data import DataDescriptions, make_samples, model_config
 

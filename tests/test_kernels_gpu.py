@@ -407,6 +407,79 @@ def test_conv3x3s2(ops, cd, B, H, W, Cin, Cout):
     assert_close(dw, wr.grad, tol, "conv wgrad")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 18, 12, 64, 128), (1, 41, 23, 128, 320), (2, 64, 40, 256, 256),
+                                            (3, 9, 7, 64, 72)])
+def test_conv3x3s2_large_tile_core(ops, monkeypatch, B, H, W, Cin, Cout):
+    """The 256x256 direct-to-LDS core on the three products of the convolution, forced on at sizes
+    below its usual threshold: output rows and columns that do not fill a tile, taps outside the
+    image (rows fetched from the block of zeros), a contraction tail in the weight gradient."""
+    monkeypatch.setenv("ATHENA_GEMM_BIG", "2")
+    cd = torch.bfloat16
+    g = torch.Generator().manual_seed(H * W + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64)
+    w = torch.randn(3, 3, Cin, Cout, generator=g, dtype=torch.float64) * 0.1
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g, dtype=torch.float64)
+    xr, wr = rounded(x, cd).requires_grad_(True), rounded(w, cd).requires_grad_(True)
+    ref = om.conv2d_same_s2(xr, wr)
+    (ref * rounded(dy, cd)).sum().backward()
+    xd, dyd = to_cd(x, cd), to_cd(dy, cd)
+    w_hwio = to_cd(w, cd)
+    w_t = to_cd(w.permute(3, 0, 1, 2), cd)          # [Cout][3][3][Cin]
+    stats = torch.empty(2 * Cout, dtype=torch.float64, device=dev())
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=cd, device=dev())
+    ops.conv3x3s2_fwd(xd, w_t, 1, out, B, H, W, Cin, Cout, stats)
+    assert_close(out, ref.detach(), 1e-2, "conv fwd")
+    o64 = out.double().cpu().reshape(-1, Cout)
+    assert_close(stats[:Cout], o64.sum(0), 1e-5, "channel sums")
+    assert_close(stats[Cout:], (o64 * o64).sum(0), 1e-5, "channel sums of squares")
+    din = torch.full((B, H, W, Cin), float("nan"), dtype=cd, device=dev())
+    ops.conv3x3s2_dgrad(dyd, w_hwio, din, B, H, W, Cin, Cout)
+    assert_close(din, xr.grad, 1e-2, "conv dgrad")
+    dw = torch.full((3, 3, Cin, Cout), float("nan"), dtype=torch.float32, device=dev())
+    ops.conv3x3s2_wgrad(xd, dyd, dw, B, H, W, Cin, Cout)
+    assert_close(dw, wr.grad, 2e-5, "conv wgrad")
+    # the same entry points on the 128x128 core give the same numbers up to the order of the fp32 sums
+    monkeypatch.setenv("ATHENA_GEMM_BIG", "0")
+    out0 = torch.empty_like(out)
+    ops.conv3x3s2_fwd(xd, w_t, 1, out0, B, H, W, Cin, Cout, stats)
+    assert_close(out, out0.double(), 1e-2, "conv fwd, two cores")
+
+
+def test_gemm_wgrad_table(ops):
+    """Weight and bias gradients of many Dense layers in one launch of the 256x256 core: shapes that
+    fill several tiles, shapes smaller than one, operands that are column blocks of wider matrices,
+    a contraction that is not a multiple of the k-tile."""
+    g = torch.Generator().manual_seed(123)
+    cd = torch.bfloat16
+    shapes = [  # rows, M (in features), N (out features), extra columns of x / dy storage
+        (1000, 256, 256, 0, 0), (130, 40, 72, 0, 8), (2000, 256, 1024, 0, 0), (777, 1024, 256, 0, 512),
+        (1056, 256, 4233, 0, 7), (64, 520, 136, 24, 0), (8000, 256, 256, 512, 512)]
+    problems, refs, keep = [], [], []
+    for rows, M, N, xa, ya in shapes:
+        ldx, ldy = (M + xa + 7) // 8 * 8, (N + ya + 7) // 8 * 8
+        X = torch.randn(rows, ldx, generator=g, dtype=torch.float64)
+        dY = torch.randn(rows, ldy, generator=g, dtype=torch.float64)
+        xo, yo = (8 if xa >= 8 else 0), (8 if ya >= 8 else 0)      # a block that starts inside the row
+        x_d, dy_d = to_cd(X, cd), to_cd(dY, cd)
+        G = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+        gb = torch.full((N,), float("nan"), dtype=torch.float32, device=dev())
+        xv, yv = x_d[:, xo:xo + M], dy_d[:, yo:yo + N]
+        problems.append((xv, yv, rows, M, N, ldx, ldy, G, gb if N != 72 else None))
+        Xr, dYr = rounded(X, cd)[:, xo:xo + M], rounded(dY, cd)[:, yo:yo + N]
+        refs.append((Xr.t() @ dYr, dYr.sum(0)))
+        keep.append((x_d, dy_d))
+    ops.gemm_wgrad_table(problems)
+    for (xv, yv, rows, M, N, ldx, ldy, G, gb), (gr, br) in zip(problems, refs):
+        assert_close(G, gr, 2e-5, "weight gradient %dx%d over %d rows" % (M, N, rows))
+        if gb is not None:
+            assert_close(gb, br, 2e-5, "bias gradient %d over %d rows" % (N, rows))
+    # a second launch of the same table (served from the cache) reproduces the first bit for bit
+    first = [p[7].clone() for p in problems]
+    ops.gemm_wgrad_table(problems)
+    assert all(torch.equal(a, p[7]) for a, p in zip(first, problems))
+
+
 @pytest.mark.parametrize("cd", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 21, 12, 1, 16), (1, 10, 9, 3, 40), (2, 50, 40, 1, 256)])
 def test_conv_small_cin(ops, cd, B, H, W, Cin, Cout):
@@ -716,13 +789,42 @@ def test_clip_adam_and_shadows(ops):
         st = torch.tensor([step], dtype=torch.int64, device=dev())
         norms = torch.empty(len(sizes), device=dev())
         lr_out = torch.empty(1, device=dev())
-        cfg = _lib.AdamCfg(0.9, 0.999, 1e-7, 3.0, 256.0, 10.0, 1.0, 4.0, 0.5, 0.5)
+        cfg = _lib.AdamCfg(0.9, 0.999, 1e-7, 3.0, 256.0, 10.0, 1.0, 4.0, 0.5, 0.5, 0.0, 0.0, 0.0, 0.0)
         ops.clip_adam_step(p, gr.to(dev()), m, v, torch.from_numpy(offs).to(dev()), len(sizes), norms, st, cfg, lr_out)
         assert int(st.item()) == step + 1
         assert_close(lr_out, torch.tensor([lr]), 1e-5, "lr")
         assert_close(m, m_ref, 1e-5, "m")
         assert_close(v, v_ref, 1e-5, "v")
         assert_close(p, p_ref, 1e-5, "param")
+
+
+def test_expdecay_adam_schedule_and_update():
+    """ExponentialDecayAdam (reference athena/utils/learning_rate.py:89-146): the learning rate stays at
+    initial_lr until start_decay_steps, then halves every decay_steps down to final_lr; the update is
+    Keras Adam with epsilon 1e-6 through the same fused kernel."""
+    from athena_amd import ops
+    from athena_amd.runtime import ParamStore, glorot_uniform
+    from athena_amd.utils.learning_rate import ExponentialDecayAdam
+    cfg = {"initial_lr": 0.01, "decay_steps": 3, "decay_rate": 0.5, "start_decay_steps": 4, "final_lr": 0.002}
+    store = ParamStore(torch.float32, device=dev())
+    store.register("w", (16, 24), glorot_uniform(16, 24))
+    store.register("b", (24,), glorot_uniform(24, 24))
+    store.finalize(seed=2)
+    opt = ExponentialDecayAdam(dict(cfg))
+    opt.attach(store)
+    g = torch.Generator().manual_seed(9)
+    p_ref = store.params[:store.n_train].double().cpu().clone()
+    m_ref, v_ref = torch.zeros_like(p_ref), torch.zeros_like(p_ref)
+    want_lr = [0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.01, 0.005, 0.005, 0.005, 0.0025, 0.0025, 0.0025, 0.002, 0.002]
+    for step, lr in enumerate(want_lr):
+        assert abs(opt.lr(step) - lr) < 1e-12
+        grad = torch.randn(store.n_train, generator=g)
+        store.grads.copy_(grad.to(dev()))
+        opt.apply_gradients(clip_norm=0.0)
+        assert abs(float(opt.lr_t) - lr) < 1e-7 * max(1.0, lr / 1e-3), (step, float(opt.lr_t), lr)
+        om.adam_update(p_ref, grad.double(), m_ref, v_ref, step, lr, eps=1e-6)
+    assert opt.iterations == len(want_lr)
+    assert_close(store.params[:store.n_train], p_ref, 1e-5, "parameters after %d updates" % len(want_lr))
 
 
 def test_refresh_shadows(ops):
