@@ -40,6 +40,34 @@ class WgradItem(Structure):
     ]
 
 
+class LayerTailFwd(Structure):
+    """Mirror of ``athena_layer_tail_fwd_desc``."""
+    _fields_ = [
+        ("rows", c_int32), ("d_model", c_int32), ("dff", c_int32), ("reserved", c_int32),
+        ("ctx", c_void_p), ("x", c_void_p), ("wo_t", c_void_p), ("bo", c_void_p), ("gamma1", c_void_p),
+        ("beta1", c_void_p), ("w1_t", c_void_p), ("b1", c_void_p), ("w2_t", c_void_p), ("b2", c_void_p),
+        ("gamma2", c_void_p), ("beta2", c_void_p),
+        ("eps", c_float), ("drop_p", c_float), ("rng_state", c_void_p),
+        ("site_res1", c_uint32), ("site_ffn", c_uint32), ("site_res2", c_uint32), ("reserved2", c_uint32),
+        ("z1", c_void_p), ("y1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("hpre", c_void_p),
+        ("h", c_void_p), ("z2", c_void_p), ("y2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p),
+    ]
+
+
+class LayerTailBwd(Structure):
+    """Mirror of ``athena_layer_tail_bwd_desc``."""
+    _fields_ = [
+        ("rows", c_int32), ("d_model", c_int32), ("dff", c_int32), ("reserved", c_int32),
+        ("dy", c_void_p), ("z2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p), ("gamma2", c_void_p),
+        ("hpre", c_void_p), ("w2", c_void_p), ("w1", c_void_p), ("z1", c_void_p), ("mean1", c_void_p),
+        ("rstd1", c_void_p), ("gamma1", c_void_p), ("wo", c_void_p),
+        ("drop_p", c_float), ("reserved2", c_float), ("rng_state", c_void_p),
+        ("site_res1", c_uint32), ("site_ffn", c_uint32), ("site_res2", c_uint32), ("reserved3", c_uint32),
+        ("df", c_void_p), ("dh", c_void_p), ("da", c_void_p), ("dx", c_void_p), ("dctx", c_void_p),
+        ("slab2", c_void_p), ("slab1", c_void_p),
+    ]
+
+
 class AdamCfg(Structure):
     """Mirror of ``athena_adam_cfg``."""
     _fields_ = [
@@ -69,6 +97,9 @@ _SIGNATURES = {
     "athena_add_layernorm_bwd_slabs": (c_int, [c_int, c_int]),
     "athena_prepare_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _S]),
     "athena_ln_fold_batched": (c_int, [_P, c_int, c_int, _S]),
+    "athena_layer_tail_workgroups": (c_int, [c_int]),
+    "athena_layer_tail_fwd": (c_int, [POINTER(LayerTailFwd), _S]),
+    "athena_layer_tail_bwd": (c_int, [POINTER(LayerTailBwd), _S]),
     "athena_mha_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_float, _P, c_int, _P, _S]),
     "athena_mha_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,

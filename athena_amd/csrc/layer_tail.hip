@@ -1,0 +1,826 @@
+// Everything of a post-LN transformer layer that follows the attention kernel, as ONE launch per
+// direction, for d_model = 256 in bf16:
+//
+//   forward   u  = ctx Wo + bo                      z1 = x + dropout(u)     y1 = LayerNorm1(z1)
+//             hp = y1 W1 + b1    h = dropout(gelu(hp))
+//             f  = h W2 + b2                        z2 = y1 + dropout(f)    y2 = LayerNorm2(z2)
+//   backward  the same chain in reverse: LayerNorm2', W2^T, gelu', W1^T, LayerNorm1', Wo^T
+//
+// (reference athena/layers/transformer.py:296-310 and :374-388; athena/layers/attention.py:166-169
+// for the output projection).  With dff = 0 only the first line runs: an attention sub-layer that
+// is not followed by the feed-forward block (the decoder's self-attention).
+//
+// A workgroup (8 waves) owns 32 complete rows.  The row block stays on the CU from the attention
+// context to y2: every intermediate is a [32, 256] image in LDS (the hidden layer goes through in
+// 256-wide slices that are consumed by the second product as soon as they exist), LayerNorm
+// statistics are reduced across the eight waves through LDS, and only what the backward pass reads
+// again is written to memory.  The operands that are NOT row-local are the weights: wave w owns
+// output columns 32 w .. 32 w + 31 of every product, so each weight element is needed by exactly one
+// wave of the workgroup -- it is loaded from L2 straight into that wave's registers in MFMA fragment
+// layout (no LDS staging, no barrier in the contraction loop).  A "unit" is the [32 columns, 256 k]
+// weight block of one wave for one slice: 16 fragments = 64 registers.  Two units are live (the two
+// products of a hidden-layer slice); as soon as a k-block of a unit has been multiplied, its two
+// registers are reloaded with the same k-block of the unit that takes its place one slice later,
+// so every fragment is requested a whole slice ahead of its use and 16-32 KB per wave are in flight
+// throughout.  Loads return in order, so waiting for ANY later load would wait for all of these:
+// the kernels therefore issue no other global load while fragments are in flight except through
+// the same one-slice-ahead discipline -- vectors (biases, gamma, beta, row statistics) and row
+// blocks needed late are staged in LDS by the prologue.
+// Activations never move between registers and global memory directly: in accumulator layout a lane
+// owns 4 consecutive columns of 2 x 2 tiles, i.e. 8-byte pieces 16 rows apart, which reach memory as
+// 32-byte fragments of cache lines.  Every row block goes through an LDS image instead and is read
+// or written with 16 bytes per lane along rows (a wave = two full 512-byte rows).
+//
+// Bounds: each CU pulls all weights of the layer once (1.15 MB at dff = 1024); all workgroups read
+// the same weights, so that is 290 MB out of L2 per launch.  The 72 k-blocks of 4 MFMAs per wave
+// take 3.8 us of matrix time.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "common.h"
+
+#define LT_D 256
+#define LT_R 32
+#define LT_THREADS 512
+#define LT_KB 8                          // 32-wide contraction blocks of a 256-wide slice
+#define LT_IMG (LT_R * LT_D)             // elements of a [32 rows][256 k] operand image (16 KB)
+
+// Operand image: eight [32 rows][32 k] blocks, 64-byte rows; the 16-byte chunk c of row r sits at
+// position c ^ 2*((r >> 2) & 1), which spreads the 16 rows of a fragment read over all banks.
+__device__ __forceinline__ int lt_img_off(int row, int k) {
+    const int kb = k >> 5, c = (k >> 3) & 3;
+    return kb * (LT_R * 32) + (row * 4 + (c ^ (((row >> 2) & 1) << 1))) * 8 + (k & 7);
+}
+
+struct LtUnit {
+    bf16x8_t f[LT_KB][2];
+};
+
+// Weights come fragment-tiled (see athena_refresh_shadows): blocks of 512 elements = 16 rows x 32
+// contraction indices in lane order, nb-major.  With row-major weights a fragment load touches 16
+// rows a power-of-two stride apart -- 16 half-used cache lines on a quarter (or one) of the L2
+// channels -- and the kernel ran 1.5x longer.
+// Address of this lane's part of a unit: rows n0 .. n0 + 31 of W (``kdim`` contraction indices per
+// row), contraction indices from k0.
+__device__ __forceinline__ const bf16_t* lt_unit_ptr(const bf16_t* W, long kdim, int n0, int k0, int lane) {
+    return W + (long)n0 * kdim + (k0 >> 5) * 512 + lane * 8;
+}
+// Request k-block kb of a unit (both 16-row halves; ld = contraction indices per row).
+__device__ __forceinline__ void lt_load_slot(LtUnit& u, int kb, const bf16_t* __restrict__ p, long ld) {
+    u.f[kb][0] = *(const bf16x8_t*)(p + kb * 512);
+    u.f[kb][1] = *(const bf16x8_t*)(p + 16 * ld + kb * 512);
+}
+__device__ __forceinline__ void lt_load_unit(LtUnit& u, const bf16_t* __restrict__ p, long ld) {
+#pragma unroll
+    for (int kb = 0; kb < LT_KB; ++kb) lt_load_slot(u, kb, p, ld);
+}
+
+// acc[i][j] += rows 16 i .. of the image times the unit's columns 16 j ..; element r of acc[i][j]
+// is the output at row 16 i + (lane & 15), column n0 + 16 j + 4 (lane >> 4) + r.  With ROLL each
+// k-block of the unit is requested again from ``next`` as soon as it has been multiplied (a
+// compile-time choice: behind a run-time branch the compiler has to place its waits for the path
+// that issued no loads, and every use of a fragment would then wait for the newest requests too).
+template <bool ROLL>
+__device__ __forceinline__ void lt_mul_unit(f32x4_t (&acc)[2][2], LtUnit& u, const bf16_t* img, int lane,
+                                            const bf16_t* __restrict__ next, long next_ld) {
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+#pragma unroll
+    for (int kb = 0; kb < LT_KB; ++kb) {
+        const bf16x8_t a0 = *(const bf16x8_t*)(img + lt_img_off(fr, kb * 32 + fk));
+        const bf16x8_t a1 = *(const bf16x8_t*)(img + lt_img_off(16 + fr, kb * 32 + fk));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a0, acc[0][j], 0, 0, 0);
+            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a1, acc[1][j], 0, 0, 0);
+        }
+        if (ROLL) lt_load_slot(u, kb, next, next_ld);
+    }
+}
+
+__device__ __forceinline__ void lt_zero(f32x4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+}
+
+// dropout multipliers of the four consecutive elements base .. base + 3, base even (same decisions
+// as dropout_mult)
+__device__ __forceinline__ void lt_dropout4(uint64_t key, uint64_t base, uint32_t thresh, float scale, float (&m)[4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t h = rng_u32(key, (base >> 1) + i);
+        m[2 * i] = (h & 0xffffu) >= thresh ? scale : 0.f;
+        m[2 * i + 1] = (h >> 16) >= thresh ? scale : 0.f;
+    }
+}
+
+__device__ __forceinline__ void lt_store4(bf16_t* p, const float (&v)[4]) {
+    const bf16x4_t t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4_t*)p = t;
+}
+__device__ __forceinline__ float lt_round(float v) { return (float)(bf16_t)v; }
+
+// ---- row blocks between global memory and LDS images: 1024 pieces of 16 bytes, two per thread;
+// piece q = row q / 32, columns 8 (q % 32) .. + 7 of the block.
+struct LtTile {
+    bf16x8_t v[2];
+};
+// rows row0 .. row0 + 31 (clamped to the last row), columns col0 .. col0 + 255 of src (row stride ld)
+__device__ __forceinline__ void lt_tile_load(LtTile& t, const bf16_t* __restrict__ src, long ld, int col0, int row0,
+                                             int rows, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = tid + u * LT_THREADS;
+        t.v[u] = *(const bf16x8_t*)(src + (long)min(row0 + (q >> 5), rows - 1) * ld + col0 + (q & 31) * 8);
+    }
+}
+__device__ __forceinline__ void lt_tile_to_img(bf16_t* img, const LtTile& t, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = tid + u * LT_THREADS;
+        *(bf16x8_t*)(img + lt_img_off(q >> 5, (q & 31) * 8)) = t.v[u];
+    }
+}
+__device__ __forceinline__ void lt_img_to_global(const bf16_t* img, bf16_t* __restrict__ dst, long ld, int col0,
+                                                 int row0, int rows, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = tid + u * LT_THREADS;
+        const int r = q >> 5;
+#ifdef LT_X_NOSTORE
+        if (row0 + r < rows && ld == 12345)
+#else
+        if (row0 + r < rows)
+#endif
+            *(bf16x8_t*)(dst + (long)(row0 + r) * ld + col0 + (q & 31) * 8) = *(const bf16x8_t*)(img + lt_img_off(r, (q & 31) * 8));
+    }
+}
+// the four values of an image a lane owns in accumulator layout (row r, columns n .. n + 3, n % 4 == 0)
+__device__ __forceinline__ bf16x4_t lt_img_get4(const bf16_t* img, int r, int n) {
+    return *(const bf16x4_t*)(img + lt_img_off(r, n));
+}
+
+// Two sums per row at once: the lane's own values are already added up in a[i], b[i]; the four lanes
+// that share a row inside a wave fold by shuffles, the eight waves through LDS (one barrier; the
+// caller separates two uses of ``red`` ([2][8][32] floats) by another barrier).
+__device__ __forceinline__ void lt_row_sums2(float (&a)[2], float (&b)[2], float* red, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[i] += __shfl_xor(a[i], 16, 64);
+        b[i] += __shfl_xor(b[i], 16, 64);
+        a[i] += __shfl_xor(a[i], 32, 64);
+        b[i] += __shfl_xor(b[i], 32, 64);
+        if (lane < 16) {
+            red[wave * LT_R + 16 * i + lane] = a[i];
+            red[8 * LT_R + wave * LT_R + 16 * i + lane] = b[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float t = 0.f, u = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            t += red[w * LT_R + 16 * i + (lane & 15)];
+            u += red[8 * LT_R + w * LT_R + 16 * i + (lane & 15)];
+        }
+        a[i] = t;
+        b[i] = u;
+    }
+}
+
+// z = res + dropout(acc + bias), y = LayerNorm(z).  v comes in as the accumulators and leaves as y
+// (rounded to bf16, which is what the next sub-layer and the backward pass see).  z and y go into
+// the LDS images zimg / yimg (the caller copies them out after its next barrier); mean / rstd go
+// straight to memory.  bias, gamma, beta: LDS.  red: two arrays of [8][32] floats.  One barrier inside,
+// between writing z and writing y.
+__device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res)[2][2][4], const float* bias,
+                                          const float* gamma, const float* beta, float eps, uint32_t thresh,
+                                          float dscale, uint64_t key, int row0, int rows, int wave, int lane,
+                                          float* __restrict__ mean, float* __restrict__ rstd, float* red, bf16_t* zimg,
+                                          bf16_t* yimg) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 16 * i + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 32 * wave + 16 * j + 4 * fq;
+            const float4 b4 = *(const float4*)(bias + n);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};
+            if (thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, thresh, dscale, dm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[i][j][r] = lt_round(res[i][j][r] + (v[i][j][r] + bb[r]) * dm[r]);
+                s[i] += v[i][j][r];
+            }
+            lt_store4(zimg + lt_img_off(16 * i + fr, n), v[i][j]);
+        }
+    }
+    // statistics of the wave's own 32 columns (mean, sum of squared deviations from it) by shuffles,
+    // then the eight pairs of a row are merged behind ONE barrier: the sum of squares about the row
+    // mean is sum_w [M2_w + 32 (mean_w - mean)^2] -- no cancellation, no second pass over the block
+    float mu[2], q[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s[i] += __shfl_xor(s[i], 16, 64);
+        s[i] += __shfl_xor(s[i], 32, 64);
+        const float mw = s[i] * (1.f / 32.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dv = v[i][j][r] - mw;
+                m2 += dv * dv;
+            }
+        m2 += __shfl_xor(m2, 16, 64);
+        m2 += __shfl_xor(m2, 32, 64);
+        if (lane < 16) {
+            red[wave * LT_R + 16 * i + lane] = mw;
+            red[8 * LT_R + wave * LT_R + 16 * i + lane] = m2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float mws[8], t = 0.f, u = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            mws[w] = red[w * LT_R + 16 * i + fr];
+            t += mws[w];
+            u += red[8 * LT_R + w * LT_R + 16 * i + fr];
+        }
+        mu[i] = t * 0.125f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) u += 32.f * (mws[w] - mu[i]) * (mws[w] - mu[i]);
+        q[i] = u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 16 * i + fr;
+        const float rs = rsqrtf(q[i] * (1.f / LT_D) + eps);
+        if (wave == 0 && fq == 0 && row < rows) {
+            mean[row] = mu[i];
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 32 * wave + 16 * j + 4 * fq;
+            const float4 g4 = *(const float4*)(gamma + n);
+            const float4 t4 = *(const float4*)(beta + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][j][r] = lt_round((v[i][j][r] - mu[i]) * rs * gg[r] + tt[r]);
+            lt_store4(yimg + lt_img_off(16 * i + fr, n), v[i][j]);
+        }
+    }
+}
+
+#ifdef LT_STAMPS
+__device__ unsigned long long lt_stamps[64];
+#define LT_STAMP(i) do { if (blockIdx.x == 7 && threadIdx.x == 0) lt_stamps[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int athena_layer_tail_debug_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lt_stamps), sizeof(lt_stamps));
+}
+#else
+#define LT_STAMP(i) do { } while (0)
+#endif
+
+#define LT_MAX_DFF 2048                  // the first Dense's bias is staged in LDS
+
+struct LtFwd {
+    int rows, dff;
+    const bf16_t* ctx;
+    const bf16_t* x;
+    const bf16_t* wo;       // tiled, rows = 256 outputs
+    const float* bo;
+    const float* gamma1;
+    const float* beta1;
+    const bf16_t* w1;       // tiled, rows = dff outputs
+    const float* b1;
+    const bf16_t* w2;       // tiled, rows = 256 outputs, dff contraction indices
+    const float* b2;
+    const float* gamma2;
+    const float* beta2;
+    float eps, dscale;
+    uint32_t thresh;
+    const uint64_t* rng_state;
+    uint32_t site_res1, site_ffn, site_res2;
+    bf16_t* z1;
+    bf16_t* y1;
+    float* mean1;
+    float* rstd1;
+    bf16_t* hpre;
+    bf16_t* h;
+    bf16_t* z2;
+    bf16_t* y2;
+    float* mean2;
+    float* rstd2;
+};
+
+template <bool FFN>
+__global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd p) {
+    // images: [0] ctx, then hidden slices (even)  [1] hidden slices (odd)  [2] y1
+    //         [3], [4] staging: x, pre-activation slices (even / odd), z1, z2, y2
+    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 5 : 4][LT_IMG];
+    __shared__ __attribute__((aligned(16))) float vecs[6][LT_D];         // bo gamma1 beta1 b2 gamma2 beta2
+    __shared__ __attribute__((aligned(16))) float b1s[FFN ? LT_MAX_DFF : 4];
+    __shared__ float red[2 * 8 * LT_R];
+    bf16_t* const img_a = imgs[0];
+    bf16_t* const img_h = imgs[1];
+    bf16_t* const img_y = imgs[2];
+    bf16_t* const st0 = imgs[3];
+    bf16_t* const st1 = imgs[FFN ? 4 : 0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row0 = blockIdx.x * LT_R;
+    const int nslice = FFN ? p.dff / LT_D : 0;
+    const int n0 = 32 * wave;
+
+    LT_STAMP(0);
+    // ---- everything small first: these are the last loads that are waited for as a group
+    LtTile tc, tx;
+    lt_tile_load(tc, p.ctx, LT_D, 0, row0, p.rows, tid);
+    lt_tile_load(tx, p.x, LT_D, 0, row0, p.rows, tid);
+    const bool hi = tid >= LT_D;
+    const int ve = tid & (LT_D - 1);
+    float vv[3], bv[LT_MAX_DFF / LT_THREADS];
+    vv[0] = (hi ? p.gamma1 : p.bo)[ve];
+    vv[1] = (hi && !FFN) ? 0.f : (hi ? p.b2 : p.beta1)[ve];
+    vv[2] = FFN ? (hi ? p.beta2 : p.gamma2)[ve] : 0.f;
+#pragma unroll
+    for (int t = 0; t < LT_MAX_DFF / LT_THREADS; ++t) {
+        const int e = tid + t * LT_THREADS;
+        bv[t] = (FFN && e < p.dff) ? p.b1[e] : 0.f;
+    }
+    // ---- weights: the projection, and slice 0 of the first Dense
+    LtUnit ua, ub;
+    lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
+    if (FFN) lt_load_unit(ub, lt_unit_ptr(p.w1, LT_D, n0, 0, lane), LT_D);
+    __builtin_amdgcn_sched_barrier(0);
+    lt_tile_to_img(img_a, tc, tid);
+    lt_tile_to_img(st0, tx, tid);
+    vecs[hi][ve] = vv[0];
+    vecs[2 + hi][ve] = vv[1];
+    vecs[4 + hi][ve] = vv[2];
+    if (FFN) {
+#pragma unroll
+        for (int t = 0; t < LT_MAX_DFF / LT_THREADS; ++t) b1s[tid + t * LT_THREADS] = bv[t];
+    }
+    __syncthreads();
+    LT_STAMP(1);
+
+    float res[2][2][4];                                         // the residual input, in accumulator layout
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x4_t t = lt_img_get4(st0, 16 * i + fr, n0 + 16 * j + 4 * fq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) res[i][j][r] = (float)t[r];
+        }
+    f32x4_t acc[2][2];
+    float v[2][2][4];
+    lt_zero(acc);
+    // ctx Wo; the projection's registers are refilled with slice 0 of the second Dense
+    lt_mul_unit<FFN>(acc, ua, img_a, lane, lt_unit_ptr(p.w2, p.dff, n0, 0, lane), p.dff);
+    LT_STAMP(2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][j][r] = acc[i][j][r];
+    uint64_t key = 0;
+    if (p.thresh) key = rng_key(p.rng_state, p.site_res1);
+    // z1 -> st1 (st0 may still be read for x by slower waves), y1 -> img_y
+    lt_add_ln(v, res, vecs[0], vecs[1], vecs[2], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean1,
+              p.rstd1, red, FFN ? st1 : st0, img_y);
+    __syncthreads();                                         // z1 and y1 images complete; img_a free again
+    LT_STAMP(3);
+    lt_img_to_global(FFN ? st1 : st0, p.z1, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global(img_y, p.y1, LT_D, 0, row0, p.rows, tid);
+    LT_STAMP(4);
+    if (!FFN) return;
+
+    // v now holds y1 (the residual of the second half)
+    f32x4_t facc[2][2];
+    lt_zero(facc);
+    uint64_t hkey = 0;
+    if (p.thresh) hkey = rng_key(p.rng_state, p.site_ffn);
+    auto slice = [&](int c, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        bf16_t* himg = (c & 1) ? img_h : img_a;
+        bf16_t* pimg = (c & 1) ? st1 : st0;
+        lt_zero(acc);
+        lt_mul_unit<MORE>(acc, ub, img_y, lane, lt_unit_ptr(p.w1, LT_D, (c + 1) * LT_D + n0, 0, lane), LT_D);  // y1 W1[slice c]
+        LT_STAMP(8 + 5 * c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + 16 * i + fr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = n0 + 16 * j + 4 * fq;                              // column inside the slice
+                const int n = c * LT_D + nl;
+                const float4 b4 = *(const float4*)(b1s + n);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                float pre[4], hv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.thresh) lt_dropout4(hkey, (uint64_t)row * p.dff + n, p.thresh, p.dscale, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pre[r] = acc[i][j][r] + bb[r];
+                    hv[r] = gelu_tanh_f(pre[r]) * dm[r];
+                }
+                lt_store4(pimg + lt_img_off(16 * i + fr, nl), pre);
+                lt_store4(himg + lt_img_off(16 * i + fr, nl), hv);
+            }
+        }
+        LT_STAMP(9 + 5 * c);
+        __syncthreads();                                     // slice c of the hidden layer is in LDS
+        LT_STAMP(10 + 5 * c);
+        lt_img_to_global(pimg, p.hpre, p.dff, c * LT_D, row0, p.rows, tid);
+        lt_img_to_global(himg, p.h, p.dff, c * LT_D, row0, p.rows, tid);
+        LT_STAMP(11 + 5 * c);
+        lt_mul_unit<MORE>(facc, ua, himg, lane, lt_unit_ptr(p.w2, p.dff, n0, (c + 1) * LT_D, lane), p.dff);  // += h[slice c] W2[slice c, :]
+        LT_STAMP(12 + 5 * c);
+    };
+    for (int c = 0; c + 1 < nslice; ++c) slice(c, std::true_type{});
+    slice(nslice - 1, std::false_type{});
+    float f[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[i][j][r] = facc[i][j][r];
+    if (p.thresh) key = rng_key(p.rng_state, p.site_res2);
+    // the images of the parity the last slice did not use are free: no wave reads them any more
+    bf16_t* zimg = (nslice & 1) ? st1 : st0;
+    bf16_t* yimg = (nslice & 1) ? img_h : img_a;
+    lt_add_ln(f, v, vecs[3], vecs[4], vecs[5], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean2,
+              p.rstd2, red, zimg, yimg);
+    LT_STAMP(5);
+    __syncthreads();
+    lt_img_to_global(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
+    LT_STAMP(6);
+}
+
+// ------------------------------------------------------------------------------------- backward
+// dz = LayerNorm'(dy) for the rows / columns this lane owns, and this workgroup's partial column
+// sums for dgamma / dbeta into ``slab`` ([2][256], one slab per workgroup: every column belongs to
+// one wave, so the slab is written without atomics).  dy comes in as g, dz leaves in g; zv holds
+// the LayerNorm input, mean / rstd (indexed by the row inside the block) and gamma live in LDS.
+__device__ __forceinline__ void lt_ln_bwd(float (&g)[2][2][4], const bf16x4_t (&zv)[2][2], const float* mean,
+                                          const float* rstd, const float* gamma, int row0, int rows, int wave, int lane,
+                                          float* red, float* __restrict__ slab) {
+    const int fr = lane & 15, fq = lane >> 4;
+    float xh[2][2][4], rs[2], c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+    float pg[2][4], pb[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pg[j][r] = 0.f; pb[j][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool live = row0 + 16 * i + fr < rows;
+        const float mu = mean[16 * i + fr];
+        rs[i] = rstd[16 * i + fr];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 32 * wave + 16 * j + 4 * fq;
+            const float4 g4 = *(const float4*)(gamma + n);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = live ? g[i][j][r] : 0.f;
+                xh[i][j][r] = live ? ((float)zv[i][j][r] - mu) * rs[i] : 0.f;
+                pg[j][r] += d * xh[i][j][r];
+                pb[j][r] += d;
+                g[i][j][r] = d * gg[r];
+                c1[i] += g[i][j][r];
+                c2[i] += g[i][j][r] * xh[i][j][r];
+            }
+        }
+    }
+    // column sums over the 32 rows: lanes with equal (lane >> 4) hold the same columns
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = pg[j][r], b = pb[j][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if (fr == 0) {
+                const int n = 32 * wave + 16 * j + 4 * fq + r;
+                slab[n] = a;
+                slab[LT_D + n] = b;
+            }
+        }
+    lt_row_sums2(c1, c2, red, wave, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float m1 = c1[i] * (1.f / LT_D), m2 = c2[i] * (1.f / LT_D);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[i][j][r] = rs[i] * (g[i][j][r] - m1 - xh[i][j][r] * m2);
+    }
+}
+
+struct LtBwd {
+    int rows, dff;
+    const bf16_t* dy;        // gradient of the layer output (of y1 when dff == 0)
+    const bf16_t* z2;
+    const float* mean2;
+    const float* rstd2;
+    const float* gamma2;
+    const bf16_t* hpre;
+    const bf16_t* w2;        // second Dense, tiled, rows = dff inputs
+    const bf16_t* w1;        // first Dense, tiled, rows = 256 inputs, dff contraction indices
+    const bf16_t* z1;
+    const float* mean1;
+    const float* rstd1;
+    const float* gamma1;
+    const bf16_t* wo;        // output projection, tiled, rows = inputs
+    float dscale;
+    uint32_t thresh;
+    const uint64_t* rng_state;
+    uint32_t site_res1, site_ffn, site_res2;
+    bf16_t* df;              // gradient of the second Dense's output (after the dropout mask)
+    bf16_t* dh;              // gradient of the first Dense's pre-activation
+    bf16_t* da;              // gradient of the projection's output (after the dropout mask)
+    bf16_t* dx;              // gradient of the residual input
+    bf16_t* dctx;            // gradient of the attention context
+    float* slab2;            // [workgroups][2][256]
+    float* slab1;
+};
+
+template <bool FFN>
+__global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd p) {
+    // images: [0] df, later da  [1] z1  [2], [3] dh slices (even / odd); before the slices dy and z2,
+    //         after them dx and dctx  [4], [5] pre-activation slices (even / odd)
+    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 6 : 4][LT_IMG];
+    __shared__ __attribute__((aligned(16))) float gam[2][LT_D];          // gamma2, gamma1
+    __shared__ float stat[4][LT_R];                                      // mean2 rstd2 mean1 rstd1
+    __shared__ float red[2 * 8 * LT_R];
+    __shared__ f32x4_t park[FFN ? 4 : 1][LT_THREADS];                    // dz2 of each thread while the slices run
+    bf16_t* const img_a = imgs[0];
+    bf16_t* const img_z1 = imgs[1];
+    bf16_t* const img_h0 = imgs[2];
+    bf16_t* const img_h1 = imgs[3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row0 = blockIdx.x * LT_R;
+    const int nslice = FFN ? p.dff / LT_D : 0;
+    const int n0 = 32 * wave;
+
+    // ---- everything small first (see the forward kernel)
+    LtTile tz1, tdy, tz2, thp;
+    lt_tile_load(tz1, p.z1, LT_D, 0, row0, p.rows, tid);
+    lt_tile_load(tdy, p.dy, LT_D, 0, row0, p.rows, tid);
+    if (FFN) {
+        lt_tile_load(tz2, p.z2, LT_D, 0, row0, p.rows, tid);
+        lt_tile_load(thp, p.hpre, p.dff, 0, row0, p.rows, tid);
+    }
+    const bool hi = tid >= LT_D;
+    const int ve = tid & (LT_D - 1);
+    float gv = 0.f, sv = 0.f;
+    if (hi || FFN) gv = (hi ? p.gamma1 : p.gamma2)[ve];
+    if (tid < 4 * LT_R) {
+        const int which = tid >> 5;
+        const int row = min(row0 + (tid & 31), p.rows - 1);
+        if (which >= 2 || FFN) sv = (which == 0 ? p.mean2 : which == 1 ? p.rstd2 : which == 2 ? p.mean1 : p.rstd1)[row];
+    }
+    // ---- weights
+    LtUnit ua, ub;
+    if (FFN) lt_load_unit(ua, lt_unit_ptr(p.w2, LT_D, n0, 0, lane), LT_D);       // rows of slice 0 of W2, k over d
+    else lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
+    __builtin_amdgcn_sched_barrier(0);
+    lt_tile_to_img(img_z1, tz1, tid);
+    lt_tile_to_img(img_h0, tdy, tid);
+    if (FFN) {
+        lt_tile_to_img(img_h1, tz2, tid);
+        lt_tile_to_img(imgs[4], thp, tid);
+        if (nslice > 1) lt_tile_load(thp, p.hpre, p.dff, LT_D, row0, p.rows, tid);    // slice 1, kept in registers
+    }
+    gam[hi][ve] = gv;
+    if (tid < 4 * LT_R) stat[tid >> 5][tid & 31] = sv;
+    __syncthreads();                                         // staged blocks and vectors visible
+
+    float g[2][2][4];
+    bf16x4_t zv[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 16 * j + 4 * fq;
+            const bf16x4_t t = lt_img_get4(img_h0, 16 * i + fr, n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[i][j][r] = (float)t[r];
+            if (FFN) zv[i][j] = lt_img_get4(img_h1, 16 * i + fr, n);
+        }
+    uint64_t key = 0;
+    if (FFN) {
+        lt_ln_bwd(g, zv, stat[0], stat[1], gam[0], row0, p.rows, wave, lane, red,
+                  p.slab2 + (long)blockIdx.x * 2 * LT_D);
+        // g = dz2: the gradient of y1 through the residual, and (masked) the gradient of f
+        lt_load_unit(ub, lt_unit_ptr(p.w1, p.dff, n0, 0, lane), p.dff);      // rows n0.. of W1, k over slice 0
+        if (p.thresh) key = rng_key(p.rng_state, p.site_res2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = row0 + 16 * i + fr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 16 * j + 4 * fq;
+                float dm[4] = {1.f, 1.f, 1.f, 1.f}, dfv[4];
+                if (p.thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, p.thresh, p.dscale, dm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dfv[r] = g[i][j][r] * dm[r];
+                lt_store4(img_a + lt_img_off(16 * i + fr, n), dfv);
+                park[FFN ? 2 * i + j : 0][tid] = (f32x4_t){g[i][j][0], g[i][j][1], g[i][j][2], g[i][j][3]};
+            }
+        }
+        __syncthreads();                                     // df image complete
+        lt_img_to_global(img_a, p.df, LT_D, 0, row0, p.rows, tid);
+        f32x4_t acc[2][2], dacc[2][2];
+        lt_zero(dacc);
+        uint64_t hkey = 0;
+        if (p.thresh) hkey = rng_key(p.rng_state, p.site_ffn);
+        // Pre-activations travel two slices ahead: slice c + 2 is requested (into registers) while
+        // slice c is worked on, and slice c + 1 moves from registers into its LDS image before the
+        // barrier of slice c, behind which slice c + 1 reads it.
+        auto slice = [&](int c, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            bf16_t* himg = (c & 1) ? img_h1 : img_h0;
+            const bf16_t* pimg = imgs[4 + (c & 1)];
+            lt_zero(acc);
+            // df W2[slice c]^T; the registers take slice c + 1, or the projection after the last slice
+            lt_mul_unit<true>(acc, ua, img_a, lane,
+                              MORE ? lt_unit_ptr(p.w2, LT_D, (c + 1) * LT_D + n0, 0, lane) : lt_unit_ptr(p.wo, LT_D, n0, 0, lane),
+                              LT_D);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = row0 + 16 * i + fr;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int nl = n0 + 16 * j + 4 * fq;
+                    const int n = c * LT_D + nl;
+                    const bf16x4_t hp = lt_img_get4(pimg, 16 * i + fr, nl);
+                    float dv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.thresh) lt_dropout4(hkey, (uint64_t)row * p.dff + n, p.thresh, p.dscale, dm);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dv[r] = acc[i][j][r] * dgelu_tanh_f((float)hp[r]) * dm[r];
+                    lt_store4(himg + lt_img_off(16 * i + fr, nl), dv);
+                }
+            }
+            if (MORE) {
+                lt_tile_to_img(imgs[5 - (c & 1)], thp, tid);
+                if (c + 2 < nslice) lt_tile_load(thp, p.hpre, p.dff, (c + 2) * LT_D, row0, p.rows, tid);
+            }
+            __syncthreads();                                 // slice c of dh is in LDS
+            lt_img_to_global(himg, p.dh, p.dff, c * LT_D, row0, p.rows, tid);
+            lt_mul_unit<MORE>(dacc, ub, himg, lane, lt_unit_ptr(p.w1, p.dff, n0, (c + 1) * LT_D, lane), p.dff);  // += dh[slice c] W1[:, slice c]^T
+        };
+        for (int c = 0; c + 1 < nslice; ++c) slice(c, std::true_type{});
+        slice(nslice - 1, std::false_type{});
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4_t t = park[FFN ? 2 * i + j : 0][tid];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[i][j][r] = t[r] + dacc[i][j][r];
+            }
+    }
+    // g = gradient of y1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) zv[i][j] = lt_img_get4(img_z1, 16 * i + fr, n0 + 16 * j + 4 * fq);
+    lt_ln_bwd(g, zv, stat[2], stat[3], gam[1], row0, p.rows, wave, lane, red, p.slab1 + (long)blockIdx.x * 2 * LT_D);
+    // (a barrier passed: nobody reads the dh images or, without the feed-forward part, dy any more)
+    if (p.thresh) key = rng_key(p.rng_state, p.site_res1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = row0 + 16 * i + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 16 * j + 4 * fq;
+            float dm[4] = {1.f, 1.f, 1.f, 1.f}, dav[4];
+            if (p.thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, p.thresh, p.dscale, dm);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dav[r] = g[i][j][r] * dm[r];
+            lt_store4(img_h0 + lt_img_off(16 * i + fr, n), g[i][j]);
+            lt_store4(img_a + lt_img_off(16 * i + fr, n), dav);
+        }
+    }
+    __syncthreads();                                         // da and dx images complete
+    lt_img_to_global(img_h0, p.dx, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global(img_a, p.da, LT_D, 0, row0, p.rows, tid);
+    f32x4_t cacc[2][2];
+    lt_zero(cacc);
+    lt_mul_unit<false>(cacc, ua, img_a, lane, nullptr, 0);   // da Wo^T
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float o[4] = {cacc[i][j][0], cacc[i][j][1], cacc[i][j][2], cacc[i][j][3]};
+            lt_store4(img_h1 + lt_img_off(16 * i + fr, n0 + 16 * j + 4 * fq), o);
+        }
+    __syncthreads();
+    lt_img_to_global(img_h1, p.dctx, LT_D, 0, row0, p.rows, tid);
+}
+
+// ------------------------------------------------------------------------------------- C ABI
+static bool lt_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int athena_layer_tail_workgroups(int rows) { return rows > 0 ? (rows + LT_R - 1) / LT_R : 0; }
+
+extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena_stream_t stream) {
+    ATHENA_REQUIRE(d, ATHENA_E_SHAPE, "athena_layer_tail_fwd: null descriptor");
+    ATHENA_REQUIRE(d->d_model == LT_D && d->dff >= 0 && d->dff % LT_D == 0 && d->dff <= LT_MAX_DFF, ATHENA_E_UNSUPPORTED,
+                   "athena_layer_tail_fwd: d_model %d dff %d (needs d_model 256 and dff a multiple of 256 up to %d)",
+                   d->d_model, d->dff, LT_MAX_DFF);
+    ATHENA_REQUIRE(d->rows > 0 && (long)d->rows * (d->dff > LT_D ? d->dff : LT_D) < (1L << 31), ATHENA_E_SHAPE,
+                   "athena_layer_tail_fwd: rows=%d", d->rows);
+    ATHENA_REQUIRE(d->ctx && d->x && d->wo_t && d->bo && d->gamma1 && d->beta1 && d->z1 && d->y1 && d->mean1 && d->rstd1,
+                   ATHENA_E_SHAPE, "athena_layer_tail_fwd: null operand");
+    ATHENA_REQUIRE(d->dff == 0 || (d->w1_t && d->b1 && d->w2_t && d->b2 && d->gamma2 && d->beta2 && d->hpre && d->h &&
+                                   d->z2 && d->y2 && d->mean2 && d->rstd2),
+                   ATHENA_E_SHAPE, "athena_layer_tail_fwd: null feed-forward operand");
+    ATHENA_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->rng_state), ATHENA_E_SHAPE,
+                   "athena_layer_tail_fwd: dropout arguments");
+    for (const void* q : {d->ctx, d->x, d->wo_t, (const void*)d->bo, (const void*)d->gamma1, (const void*)d->beta1,
+                          d->w1_t, (const void*)d->b1, d->w2_t, (const void*)d->b2, (const void*)d->gamma2,
+                          (const void*)d->beta2, (const void*)d->z1, (const void*)d->y1, (const void*)d->hpre,
+                          (const void*)d->h, (const void*)d->z2, (const void*)d->y2})
+        ATHENA_REQUIRE(lt_al16(q), ATHENA_E_SHAPE, "athena_layer_tail_fwd: operands must be 16-byte aligned");
+    LtFwd p;
+    p.rows = d->rows; p.dff = d->dff;
+    p.ctx = (const bf16_t*)d->ctx; p.x = (const bf16_t*)d->x;
+    p.wo = (const bf16_t*)d->wo_t; p.bo = d->bo; p.gamma1 = d->gamma1; p.beta1 = d->beta1;
+    p.w1 = (const bf16_t*)d->w1_t; p.b1 = d->b1; p.w2 = (const bf16_t*)d->w2_t; p.b2 = d->b2;
+    p.gamma2 = d->gamma2; p.beta2 = d->beta2;
+    p.eps = d->eps;
+    p.thresh = dropout_threshold(d->drop_p);
+    p.dscale = p.thresh ? 1.f / (1.f - d->drop_p) : 1.f;
+    p.rng_state = d->rng_state;
+    p.site_res1 = d->site_res1; p.site_ffn = d->site_ffn; p.site_res2 = d->site_res2;
+    p.z1 = (bf16_t*)d->z1; p.y1 = (bf16_t*)d->y1; p.mean1 = d->mean1; p.rstd1 = d->rstd1;
+    p.hpre = (bf16_t*)d->hpre; p.h = (bf16_t*)d->h;
+    p.z2 = (bf16_t*)d->z2; p.y2 = (bf16_t*)d->y2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
+    if (d->dff > 0)
+        hipLaunchKernelGGL(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(layer_tail_fwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    ATHENA_CHECK_LAUNCH("athena_layer_tail_fwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_layer_tail_bwd(const athena_layer_tail_bwd_desc* d, athena_stream_t stream) {
+    ATHENA_REQUIRE(d, ATHENA_E_SHAPE, "athena_layer_tail_bwd: null descriptor");
+    ATHENA_REQUIRE(d->d_model == LT_D && d->dff >= 0 && d->dff % LT_D == 0 && d->dff <= LT_MAX_DFF, ATHENA_E_UNSUPPORTED,
+                   "athena_layer_tail_bwd: d_model %d dff %d (needs d_model 256 and dff a multiple of 256 up to %d)",
+                   d->d_model, d->dff, LT_MAX_DFF);
+    ATHENA_REQUIRE(d->rows > 0 && (long)d->rows * (d->dff > LT_D ? d->dff : LT_D) < (1L << 31), ATHENA_E_SHAPE,
+                   "athena_layer_tail_bwd: rows=%d", d->rows);
+    ATHENA_REQUIRE(d->dy && d->z1 && d->mean1 && d->rstd1 && d->gamma1 && d->wo && d->da && d->dx && d->dctx && d->slab1,
+                   ATHENA_E_SHAPE, "athena_layer_tail_bwd: null operand");
+    ATHENA_REQUIRE(d->dff == 0 || (d->z2 && d->mean2 && d->rstd2 && d->gamma2 && d->hpre && d->w2 && d->w1 && d->df &&
+                                   d->dh && d->slab2),
+                   ATHENA_E_SHAPE, "athena_layer_tail_bwd: null feed-forward operand");
+    ATHENA_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->rng_state), ATHENA_E_SHAPE,
+                   "athena_layer_tail_bwd: dropout arguments");
+    for (const void* q : {d->dy, d->z2, (const void*)d->gamma2, d->hpre, d->w2, d->w1, d->z1, (const void*)d->gamma1,
+                          d->wo, (const void*)d->df, (const void*)d->dh, (const void*)d->da, (const void*)d->dx,
+                          (const void*)d->dctx, (const void*)d->slab1, (const void*)d->slab2})
+        ATHENA_REQUIRE(lt_al16(q), ATHENA_E_SHAPE, "athena_layer_tail_bwd: operands must be 16-byte aligned");
+    LtBwd p;
+    p.rows = d->rows; p.dff = d->dff;
+    p.dy = (const bf16_t*)d->dy; p.z2 = (const bf16_t*)d->z2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
+    p.gamma2 = d->gamma2; p.hpre = (const bf16_t*)d->hpre; p.w2 = (const bf16_t*)d->w2; p.w1 = (const bf16_t*)d->w1;
+    p.z1 = (const bf16_t*)d->z1; p.mean1 = d->mean1; p.rstd1 = d->rstd1; p.gamma1 = d->gamma1;
+    p.wo = (const bf16_t*)d->wo;
+    p.thresh = dropout_threshold(d->drop_p);
+    p.dscale = p.thresh ? 1.f / (1.f - d->drop_p) : 1.f;
+    p.rng_state = d->rng_state;
+    p.site_res1 = d->site_res1; p.site_ffn = d->site_ffn; p.site_res2 = d->site_res2;
+    p.df = (bf16_t*)d->df; p.dh = (bf16_t*)d->dh; p.da = (bf16_t*)d->da; p.dx = (bf16_t*)d->dx;
+    p.dctx = (bf16_t*)d->dctx; p.slab2 = d->slab2; p.slab1 = d->slab1;
+    if (d->dff > 0)
+        hipLaunchKernelGGL(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(layer_tail_bwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+                           (hipStream_t)stream, p);
+    ATHENA_CHECK_LAUNCH("athena_layer_tail_bwd");
+    return ATHENA_OK;
+}

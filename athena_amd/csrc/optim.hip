@@ -120,7 +120,13 @@ extern "C" int athena_clip_adam_step(float* params, const float* grads, float* m
 }
 
 // ---------------------------------------------------------------- bf16 shadows
-// one workgroup per 32x32 tile of one matrix; writes the straight copy and the transposed copy
+// one workgroup per 32x32 tile of one matrix; writes the straight copy and the transposed copy, and
+// for matrices that ask for them (offsets >= 0; dimensions multiples of 32) the two fragment-tiled
+// copies: blocks of 512 elements, block (nb, kb) = 16 rows x 32 contraction indices, element
+// 8 * lane + e of a block = row 16 nb + (lane & 15), contraction index 32 kb + 8 (lane >> 4) + e,
+// blocks ordered nb-major.  "tiled": rows = the matrix' rows, contraction over its columns;
+// "tiled_t": rows = its columns, contraction over its rows.  A wave reads a block with one
+// 16-bytes-per-lane load of 1 KB of consecutive memory and has an MFMA B fragment in registers.
 __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __restrict__ params,
                                                               bf16_t* __restrict__ shadow,
                                                               const int64_t* __restrict__ table, int nmat,
@@ -128,10 +134,11 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
     __shared__ float tile[32][33];
     const long tid = blockIdx.x;
     int mi = find_segment(tile_prefix, nmat, tid);
-    const int64_t* d = table + 7L * mi;
+    const int64_t* d = table + 9L * mi;
     const long src = d[0];
     const int rows = (int)d[1], cols = (int)d[2];
     const long dst = d[3], ld_s = d[4], dst_t = d[5], ld_t = d[6];
+    const long til = d[7], til_t = d[8];
     const int tcols = (cols + 31) / 32;
     const int local = (int)(tid - tile_prefix[mi]);
     const int tr = local / tcols, tc = local - tr * tcols;
@@ -161,6 +168,18 @@ __global__ __launch_bounds__(256) void refresh_shadows_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)tile[x4 + k][y];
             *(uint2*)(shadow + dst_t + (long)c * ld_t + r) = pk.u;
+        }
+        if (til >= 0 && til_t >= 0) {
+            // two blocks of each tiled copy lie inside this 32x32 tile; a thread writes 4 elements of each
+            const int b = threadIdx.x >> 7, lane = (threadIdx.x >> 1) & 63, e0 = (threadIdx.x & 1) * 4;
+            const int fr = lane & 15, k0 = (lane >> 4) * 8 + e0;
+            union { bf16_t h[4]; uint2 u; } pk;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)tile[b * 16 + fr][k0 + k];
+            *(uint2*)(shadow + til + ((long)(2 * tr + b) * (cols / 32) + tc) * 512 + lane * 8 + e0) = pk.u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)tile[k0 + k][b * 16 + fr];
+            *(uint2*)(shadow + til_t + ((long)(2 * tc + b) * (rows / 32) + tr) * 512 + lane * 8 + e0) = pk.u;
         }
         return;
     }

@@ -41,7 +41,7 @@ class MultiHeadAttention(nn.Module):
         self.wq = Dense(store, name + ".wq", d_model, d_model, init)
         self.wk = Dense(store, name + ".wk", d_model, d_model, init)
         self.wv = Dense(store, name + ".wv", d_model, d_model, init)
-        self.dense = Dense(store, name + ".dense", d_model, d_model, init)
+        self.dense = Dense(store, name + ".dense", d_model, d_model, init, tiled=True)
         # one fused bf16 copy [d, 3d] of the three projection kernels: the input gradients of the
         # projections that share an input are then a single product
         if d_model % 8 == 0:

@@ -24,20 +24,22 @@ class _Bound(nn.Module):
 class Dense(_Bound):
     """tf.keras.layers.Dense: kernel [in, out], bias [out] (zeros)."""
 
-    def __init__(self, store, name, in_features, out_features, kernel_init=None):
+    def __init__(self, store, name, in_features, out_features, kernel_init=None, tiled=False):
         super().__init__()
         self.store, self.vname = store, name
         self.in_features, self.out_features = in_features, out_features
         store.register(name + ".kernel", (in_features, out_features),
-                       kernel_init or glorot_uniform(in_features, out_features), matrix=(in_features, out_features))
+                       kernel_init or glorot_uniform(in_features, out_features), matrix=(in_features, out_features),
+                       tiled=tiled)
         store.register(name + ".bias", (out_features,), constant(0.0))
-        self.shadow = self.shadow_t = None
+        self.shadow = self.shadow_t = self.tiled = self.tiled_t = None
 
     def bind(self):
         self._bind_param("kernel", self.vname + ".kernel")
         self._bind_param("bias", self.vname + ".bias")
         if self.store.shadow is not None:
             self.shadow, self.shadow_t = self.store.shadow_views(self.vname + ".kernel")
+            self.tiled, self.tiled_t = self.store.tiled_views(self.vname + ".kernel")
 
 
 class Conv3x3Params(_Bound):

@@ -147,27 +147,34 @@ def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):
 # ----------------------------------------------------------------------------------------------
 # Multi-head attention block (reference athena/layers/attention.py:147-171)
 # ----------------------------------------------------------------------------------------------
-def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal):
+def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True):
+    """q/k/v projections, attention and (``project``) the output projection.  Without it the
+    attention context is returned in place of the block's output."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
     q, k, v = lin_fwd_group([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk), (kv_in, B * Tk, attn.wv)])
     ctx = torch.empty((B * Tq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, h, Tq), dtype=torch.float32, device=q.device)
     ops.mha_fwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, d, lse)
+    if not project:
+        return ctx, (q, k, v, ctx, lse)
     out, _ = lin_fwd(ctx, B * Tq, attn.dense)
     return out, (q, k, v, ctx, lse)
 
 
-def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, dq_in, acc_q, dkv_in, acc_kv):
-    """Writes parameter grads; adds/stores the input grads into dq_in / dkv_in (may be one tensor)."""
+def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, dq_in, acc_q, dkv_in, acc_kv,
+                  dctx=None):
+    """Writes parameter grads; adds/stores the input grads into dq_in / dkv_in (may be one tensor).
+    With ``dctx`` (the gradient of the attention context) the output projection is the caller's."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
     q, k, v, ctx, lse = saved
     Mq, Mk = B * Tq, B * Tk
-    # without dropout the caller's dout IS the buffer the input gradients are accumulated into
-    safe = dout.data_ptr() not in (dq_in.data_ptr(), dkv_in.data_ptr())
-    lin_bwd_w(ctx, dout, Mq, attn.dense, d, d, defer=safe)
-    dctx = lin_bwd_x(dout, Mq, attn.dense, d)
+    if dctx is None:
+        # without dropout the caller's dout IS the buffer the input gradients are accumulated into
+        safe = dout.data_ptr() not in (dq_in.data_ptr(), dkv_in.data_ptr())
+        lin_bwd_w(ctx, dout, Mq, attn.dense, d, d, defer=safe)
+        dctx = lin_bwd_x(dout, Mq, attn.dense, d)
     delta = torch.empty_like(lse)
     fused = attn.qkv_shadow() if q.dtype == torch.bfloat16 else None
     same_in = q_in.data_ptr() == kv_in.data_ptr() and Mq == Mk and dq_in.data_ptr() == dkv_in.data_ptr()
@@ -231,6 +238,31 @@ def _params_of(*mods):
     return ps
 
 
+def _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng):
+    """Backward pass of an encoder layer whose forward pass ran ``ops.layer_tail_fwd``."""
+    M, d = dy.shape
+    dff = layer.ffn0.out_features
+    attn = layer.self_attn
+    r = ops.layer_tail_bwd(dy, t, attn.dense, layer.norm1, layer.ffn0, layer.ffn1, layer.norm2, p, rng,
+                           layer.site_res1, layer.site_ffn_h, layer.site_res2)
+    with weight_grad_group():
+        if r is None:
+            # no backward pass to fold the LayerNorm sums at the end of: the separate kernels
+            d_y1, df = ops.add_layernorm_bwd(dy, t["z2"], t["mean2"], t["rstd2"], layer.norm2.gamma, p, rng,
+                                             layer.site_res2, layer.norm2.gamma.grad, layer.norm2.beta.grad)
+            ffn_bwd(df, t["y1"], M, layer, (t["hpre"], t["h"]), p, rng, d_y1)
+            dx, da = ops.add_layernorm_bwd(d_y1, t["z1"], t["mean1"], t["rstd1"], layer.norm1.gamma, p, rng,
+                                           layer.site_res1, layer.norm1.gamma.grad, layer.norm1.beta.grad)
+            mha_block_bwd(da, x2, x2, attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
+            return dx
+        df, dh, da, dx, dctx = r
+        lin_bwd_w(t["h"], df, M, layer.ffn1, dff, d)
+        lin_bwd_w(t["y1"], dh, M, layer.ffn0, d, dff)
+        lin_bwd_w(s_att[3], da, M, attn.dense, d, d)
+        mha_block_bwd(None, x2, x2, attn, s_att, B, T, T, key_mask, False, dx, True, dx, True, dctx=dctx)
+    return dx
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """TransformerEncoderLayer.call (reference athena/layers/transformer.py:296-310)."""
 
@@ -241,13 +273,23 @@ class EncoderLayerFn(torch.autograd.Function):
         rng = layer.store.rng_state
         p = layer.rate if training else 0.0
         x2 = x.reshape(M, d)
+        ctx.layer, ctx.key_mask, ctx.p, ctx.shape = layer, key_mask, p, (B, T, d)
+        ctx.tail = None
+        if ops.layer_tail_ok(x2, d, layer.self_attn.dense, layer.ffn0, layer.ffn1):
+            # everything after the attention kernel in one launch
+            c, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, False, project=False)
+            t = ops.layer_tail_fwd(c, x2.contiguous(), layer.self_attn.dense, layer.norm1, layer.ffn0, layer.ffn1,
+                                   layer.norm2, LN_EPS, p, rng, layer.site_res1, layer.site_ffn_h, layer.site_res2)
+            y2 = t.pop("y2")
+            ctx.tail = t
+            ctx.saved = (x2, s_att)
+            return y2.view(B, T, d)
         a, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, False)
         z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(x2, a, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
                                                      layer.site_res1)
         f, s_ffn = ffn_fwd(y1, M, layer, p, rng)
         z2, y2, mean2, rstd2 = ops.add_layernorm_fwd(y1, f, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng,
                                                      layer.site_res2)
-        ctx.layer, ctx.key_mask, ctx.p, ctx.shape = layer, key_mask, p, (B, T, d)
         ctx.saved = (x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2)
         return y2.view(B, T, d)
 
@@ -257,9 +299,15 @@ class EncoderLayerFn(torch.autograd.Function):
         B, T, d = ctx.shape
         M = B * T
         rng = layer.store.rng_state
+        dy = dy.contiguous().view(M, d)
+        if ctx.tail is not None:
+            t, ctx.tail = ctx.tail, None
+            x2, s_att = ctx.saved
+            ctx.saved = None
+            dx = _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng)
+            return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
         x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2 = ctx.saved
         ctx.saved = None
-        dy = dy.contiguous().view(M, d)
         with weight_grad_group():
             d_y1, df = ops.add_layernorm_bwd(dy, z2, mean2, rstd2, layer.norm2.gamma, p, rng, layer.site_res2,
                                              layer.norm2.gamma.grad, layer.norm2.beta.grad)

@@ -20,8 +20,8 @@ class TransformerEncoderLayer(nn.Module):
         self.store, self.rate = store, dropout
         self.self_attn = MultiHeadAttention(store, name + ".self_attn", d_model, nhead, unidirectional, look_ahead)
         init = truncated_normal(0.02)
-        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init)
-        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init)
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=True)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=True)
         self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
         self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
         self.site_res1, self.site_ffn_h, self.site_res2 = store.new_site(), store.new_site(), store.new_site()
@@ -43,8 +43,8 @@ class TransformerDecoderLayer(nn.Module):
         self.attn1 = MultiHeadAttention(store, name + ".attn1", d_model, nhead)
         self.attn2 = MultiHeadAttention(store, name + ".attn2", d_model, nhead)
         init = truncated_normal(0.02)
-        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init)
-        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init)
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=True)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=True)
         self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
         self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
         self.norm3 = LayerNormParams(store, name + ".norm3", d_model)

@@ -41,12 +41,13 @@ def make_positional_encoding(position, d_model):
 class Slot:
     """One registered variable: name, shape, offset into the flat buffers."""
     __slots__ = ("name", "shape", "numel", "offset", "trainable", "matrix", "sh_off", "sh_ld", "sht_off",
-                 "sht_ld", "init", "group")
+                 "sht_ld", "init", "group", "tiled", "tl_off", "tlt_off")
 
-    def __init__(self, name, shape, trainable, matrix, init):
+    def __init__(self, name, shape, trainable, matrix, init, tiled=False):
         self.name, self.shape, self.trainable, self.matrix, self.init = name, tuple(shape), trainable, matrix, init
         self.numel = int(np.prod(shape))
         self.offset = self.sh_off = self.sh_ld = self.sht_off = self.sht_ld = self.group = None
+        self.tiled, self.tl_off, self.tlt_off = tiled, -1, -1
 
 
 class ParamStore:
@@ -67,13 +68,15 @@ class ParamStore:
         self.shadow_groups = []
 
     # ---- registration (before finalize) -------------------------------------------------
-    def register(self, name, shape, init, trainable=True, matrix=None):
-        """``matrix`` = (rows, cols) if the variable is used as a GEMM operand (gets bf16 shadows)."""
+    def register(self, name, shape, init, trainable=True, matrix=None, tiled=False):
+        """``matrix`` = (rows, cols) if the variable is used as a GEMM operand (gets bf16 shadows);
+        ``tiled`` asks for the two fragment-tiled copies as well (``tiled_views``; given when both
+        dimensions are multiples of 32)."""
         if self.finalized:
             raise RuntimeError("ParamStore: register after finalize")
         if name in self.by_name:
             raise KeyError("ParamStore: duplicate variable %s" % name)
-        s = Slot(name, shape, trainable, matrix, init)
+        s = Slot(name, shape, trainable, matrix, init, tiled)
         self.slots.append(s)
         self.by_name[name] = s
         return s
@@ -154,7 +157,11 @@ class ParamStore:
                     soff += ops.roundup(r * s.sh_ld, ALIGN)
                     s.sht_off = soff
                     soff += ops.roundup(c * s.sht_ld, ALIGN)
-                table += [s.offset, r, c, s.sh_off, s.sh_ld, s.sht_off, s.sht_ld]
+                if s.tiled and r % 32 == 0 and c % 32 == 0 and s.sh_ld % 4 == 0 and s.sht_ld % 4 == 0:
+                    s.tl_off = soff
+                    s.tlt_off = soff + r * c
+                    soff += ops.roundup(2 * r * c, ALIGN)
+                table += [s.offset, r, c, s.sh_off, s.sh_ld, s.sht_off, s.sht_ld, s.tl_off, s.tlt_off]
                 prefix.append(prefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
             self.shadow = torch.zeros(max(soff, 8), dtype=torch.bfloat16, device=dev)
             self.sh_table = torch.tensor(table, dtype=torch.int64, device=dev)
@@ -183,6 +190,15 @@ class ParamStore:
         a = self.shadow[s.sh_off:s.sh_off + r * s.sh_ld].view(r, s.sh_ld)
         b = self.shadow[s.sht_off:s.sht_off + c * s.sht_ld].view(c, s.sht_ld)
         return a, b
+
+    def tiled_views(self, name):
+        """(tiled copy with the matrix' rows as rows, tiled copy with its columns as rows) -- flat bf16
+        tensors in the block layout ``athena_refresh_shadows`` documents -- or (None, None)."""
+        s = self.by_name[name]
+        if s.tl_off < 0:
+            return None, None
+        n = s.matrix[0] * s.matrix[1]
+        return self.shadow[s.tl_off:s.tl_off + n], self.shadow[s.tlt_off:s.tlt_off + n]
 
     def group_shadow_views(self, name):
         """(fused row-major copy [in, sum out_i], fused transposed copy [sum out_i, in]) of the

@@ -66,9 +66,10 @@ def build(wl, precision, seed):
 
 
 def gemm_flops_parts(wl):
-    """Algorithmic FLOPs of one training step (forward x 3) by GEMM family: the implicit-GEMM
-    second convolution, the vocabulary projections, and every other Dense layer (x_net Dense,
-    q/k/v/o projections and FFN of the encoder and decoder layers)."""
+    """Algorithmic FLOPs of one training step by GEMM family: the implicit-GEMM second convolution
+    (forward, input gradient, weight gradient), the forward and input-gradient products of the
+    vocabulary projections, those of every other Dense layer (x_net Dense, q/k/v/o projections and
+    FFN of the encoder and decoder layers), and the weight gradients of all Dense layers."""
     B, T, Fd = wl["B"], wl["T"], wl["feat"]
     C, d, dff, V, U = wl["num_filters"], wl["d_model"], wl["dff"], wl["vocab"] + 1, wl["U"]
     T1, F1 = (T + 1) // 2, (Fd + 1) // 2
@@ -79,7 +80,8 @@ def gemm_flops_parts(wl):
     enc = wl["enc"] * (8 * T2 * d * d + 4 * T2 * d * dff)
     dec = wl["dec"] * (8 * L * d * d + 4 * L * d * d + 4 * T2 * d * d + 4 * L * d * dff)
     heads = 2 * L * d * V + 2 * T2 * d * V
-    return {"conv2": 3.0 * B * conv2, "layer_gemm": 3.0 * B * (xdense + enc + dec), "vocab": 3.0 * B * heads}
+    return {"conv2": 3.0 * B * conv2, "layer_gemm": 2.0 * B * (xdense + enc + dec), "vocab": 2.0 * B * heads,
+            "dense_wgrad": 1.0 * B * (xdense + enc + dec + heads)}
 
 
 def gemm_flops_per_step(wl):
@@ -203,8 +205,9 @@ def gpu_plug(ms):
     torch.cuda._sleep(int(ms * gpu_plug.cycles_per_ms))
 
 
-GEMM_ENTRIES = ["athena_gemm", "athena_gemm_grouped", "athena_conv3x3s2_fwd", "athena_conv3x3s2_dgrad",
-                "athena_conv3x3s2_wgrad"]
+GEMM_ENTRIES = ["athena_gemm", "athena_gemm_grouped", "athena_gemm_wgrad_table", "athena_layer_tail_fwd",
+                "athena_layer_tail_bwd", "athena_conv3x3s2_fwd", "athena_conv3x3s2_dgrad", "athena_conv3x3s2_wgrad"]
+GEMM_FAMILIES = ("conv2", "layer_gemm", "vocab", "dense_wgrad")
 ATTN_ENTRIES = ["athena_mha_fwd", "athena_mha_bwd"]
 CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd"]
 
@@ -377,10 +380,17 @@ def main():
                 return "ctc"
             if name.startswith("athena_conv3x3s2"):
                 return "conv2"
-            if name == "athena_gemm":
+            if name == "athena_gemm_wgrad_table":
+                return "dense_wgrad"
+            if name in ("athena_gemm", "athena_gemm_grouped"):
                 d = a[0]._obj if hasattr(a[0], "_obj") else a[0]
-                return "vocab" if any(x in (V, Vp) for x in (d.M, d.N, d.K)) else "layer_gemm"
-            return "layer_gemm"                     # grouped launches: q/k/v projections, a layer's weight gradients
+                if name == "athena_gemm_grouped":
+                    d = d[0]
+                if d.trans_a:
+                    return "dense_wgrad"               # a weight gradient issued on its own (x^T dy)
+                if name == "athena_gemm" and any(x in (V, Vp) for x in (d.M, d.N, d.K)):
+                    return "vocab"
+            return "layer_gemm"                     # Dense forward / input gradient, fused layer tails
         nrep = 3
         solver.train_step(ds)
         with KernelTimer(GEMM_ENTRIES + ATTN_ENTRIES + CTC_ENTRIES, classify) as kt:
@@ -392,18 +402,18 @@ def main():
         solver.hparams.enable_tf_function = was
         solver.world_size, solver._force_exchange = was_dp
         fl = gemm_flops_parts(wl)
-        g_ms, g_calls = kt.total_ms(["conv2", "layer_gemm", "vocab"])
+        g_ms, g_calls = kt.total_ms(list(GEMM_FAMILIES))
         flops = sum(fl.values())
         ach = flops * nrep / (g_ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel (+ splitk_reduce): every Dense and "
-                          "implicit-GEMM Conv2D launch of a step",
+        roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel / gemm_big_kernel / gemm_big_table_kernel / "
+                          "layer_tail_*_kernel (+ splitk_reduce): every Dense and implicit-GEMM Conv2D launch of a step",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "gemm"),
                 "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep,
                 "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_pair_cost_us": 1e3 * kt.floor_ms,
                 "flops_per_step": flops}
         parts = {}
-        for key in ("conv2", "layer_gemm", "vocab"):
+        for key in GEMM_FAMILIES:
             ms, calls = kt.total_ms([key])
             if calls == 0:
                 continue

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from oracle import ctc as octc
 from oracle import model as om
-from tests.util import TOL, assert_close, dev, rel_err, rounded, to_cd
+from tests.util import TOL, assert_close, dev, rel_err, rel_l2, rounded, to_cd
 
 pytestmark = pytest.mark.gpu
 
@@ -825,6 +825,53 @@ def test_expdecay_adam_schedule_and_update():
         om.adam_update(p_ref, grad.double(), m_ref, v_ref, step, lr, eps=1e-6)
     assert opt.iterations == len(want_lr)
     assert_close(store.params[:store.n_train], p_ref, 1e-5, "parameters after %d updates" % len(want_lr))
+
+
+def _encoder_layer_run(monkeypatch, fused, dff, B, T, rate, seed=5):
+    """One forward + backward pass of a bf16 encoder layer (d_model 256) on seeded inputs; returns the
+    output, the input gradient and a copy of all parameter gradients."""
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    monkeypatch.setenv("ATHENA_LAYER_TAIL", "1" if fused else "0")
+    store = ParamStore(torch.bfloat16, device=dev())
+    layer = TransformerEncoderLayer(store, "enc", 256, 4, dff, rate)
+    store.finalize(seed=seed)
+    bind_all(layer)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        # LayerNorm parameters and biases away from their 1 / 0 initial values
+        for name, p_ in layer.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.3 * torch.randn(p_.shape, generator=g).to(p_.device))
+    store.refresh_shadows(force=True)
+    x = torch.randn(B, T, 256, generator=g).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(B, T, 256, generator=g).to(dev()).to(torch.bfloat16)
+    store.grads.zero_()
+    y = layer(x, None, training=True)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    grads = {n: p_.grad.detach().float().clone() for n, p_ in layer.named_parameters()}
+    return y.detach().float(), x.grad.detach().float(), grads
+
+
+@pytest.mark.parametrize("dff,B,T,rate", [(1024, 4, 64, 0.0), (512, 3, 50, 0.1), (256, 1, 7, 0.1)])
+def test_layer_tail_matches_separate_kernels(ops, monkeypatch, dff, B, T, rate):
+    """The one-launch layer tail (output projection, LayerNorms, feed-forward block; reference
+    athena/layers/transformer.py:296-310) against the same layer run as separate Dense / LayerNorm
+    launches: same dropout decisions, so the two differ by bf16 rounding of intermediates only (the
+    fused kernel keeps them in fp32 where the separate kernels store bf16).  Row counts that do not
+    fill the last 32-row block are included."""
+    y0, dx0, g0 = _encoder_layer_run(monkeypatch, False, dff, B, T, rate)
+    y1, dx1, g1 = _encoder_layer_run(monkeypatch, True, dff, B, T, rate)
+    assert torch.isfinite(y1).all() and torch.isfinite(dx1).all()
+    assert rel_l2(y1, y0) < 6e-3, ("y", rel_l2(y1, y0))
+    assert rel_l2(dx1, dx0) < 1.5e-2, ("dx", rel_l2(dx1, dx0))
+    for name in g0:
+        assert torch.isfinite(g1[name]).all(), name
+        if name.endswith("wk.bias"):
+            continue        # exactly zero in exact arithmetic (a shift of all keys cancels in the softmax)
+        assert rel_l2(g1[name], g0[name]) < 1.5e-2, (name, rel_l2(g1[name], g0[name]))
 
 
 def test_refresh_shadows(ops):

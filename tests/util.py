@@ -15,6 +15,13 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / den
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2 over the whole tensor (b is the oracle)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm()) / max(float(b.norm()), 1e-30)
+
+
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
     assert e <= tol, "%s: relative error %.3e > %.1e" % (what, e, tol)
