@@ -414,16 +414,21 @@ class HorovodSolver(BaseSolver):
             idx = solver_gpus[local_rank] if solver_gpus else local_rank
             torch.cuda.set_device(idx)
         if not dist.is_initialized() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # ATHENA_DP_BACKEND=gloo rehearses several ranks on fewer GPUs (the sums go through the host)
+            backend = os.environ.get("ATHENA_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             dist.init_process_group(backend=backend)
 
     def broadcast_variables(self):
         """hvd.broadcast_variables(root_rank=0) of the model and optimizer state (solver.py:192-194)."""
         if self.world_size > 1:
             st = self.model.store
-            dist.broadcast(st.params, src=0)
-            for t in self.optimizer.variables():
-                dist.broadcast(t, src=0)
+            for t in [st.params] + list(self.optimizer.variables()):
+                if t.is_cuda and dist.get_backend() == "gloo":      # rehearsal backend: through the host
+                    host = t.cpu()
+                    dist.broadcast(host, src=0)
+                    t.copy_(host)
+                else:
+                    dist.broadcast(t, src=0)
             st.shadows_dirty = True
         self._broadcast_done = True
 
@@ -450,9 +455,10 @@ class HorovodSolver(BaseSolver):
         return 1.0 / self.world_size
 
     def _record(self, samples):
-        # Off by default: on one MI355X every extra graph boundary costs ~0.27 ms (0.8 ms for the four
-        # pieces of a 12-layer encoder), about what hiding an 84 MB exchange over 8 GPUs can win back.
-        if (self.world_size > 1 or self._force_exchange) and os.environ.get("ATHENA_DP_PIPELINE", "0") == "1":
+        # With more than one rank the exchange runs behind the backward pass, piece by piece
+        # (ATHENA_DP_PIPELINE=0: one exchange after the whole backward pass instead).  With a single
+        # rank the extra graph boundaries cost 0.2 ms of a 6 ms AISHELL step and hide nothing.
+        if (self.world_size > 1 or self._force_exchange) and os.environ.get("ATHENA_DP_PIPELINE", "1") != "0":
             try:
                 return _PipelinedGraphStep(self, samples)
             except RuntimeError as e:          # unusual parameter layout: exchange after the whole backward pass

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run on the MI355X box)")
+    # Multi-rank GPU tests start their ranks through a fork server that is launched HERE, before any
+    # test has touched the GPU: the ranks are then forked from a process that never initialised it.
+    import multiprocessing
+    from multiprocessing import forkserver
+    multiprocessing.get_context("forkserver")
+    forkserver.ensure_running()
 
 
 def pytest_collection_modifyitems(config, items):
