@@ -70,7 +70,7 @@ __global__ __launch_bounds__(ATT_BLOCK) void mha_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int w = 1; w < P; w <<= 1) acc += __shfl_xor(acc, w, 64);
             float sv = acc * scale;
-            const bool masked = sM[jj] != 0.f || (causal && (j0 + jj) > i);
+            const bool masked = sM[jj] != 0.f || (causal && (j0 + jj) > i + causal - 1);
             if (masked) sv += -1e9f;
             if (jj >= nj) sv = -INFINITY;
             s[jj] = sv;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(ATT_BLOCK) void mha_bwd_dq_kernel(const T* __restri
                 dp += __shfl_xor(dp, w, 64);
             }
             float sv = s * scale;
-            if (sM[jj] != 0.f || (causal && (j0 + jj) > i)) sv += -1e9f;
+            if (sM[jj] != 0.f || (causal && (j0 + jj) > i + causal - 1)) sv += -1e9f;
             const float p = __expf(sv - li);
             const float ds = p * (dp - di) * scale;
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(ATT_BLOCK) void mha_bwd_dkv_kernel(const T* __restr
                 dp += __shfl_xor(dp, w, 64);
             }
             float sv = s * scale;
-            if (kmask || (causal && j > (i0 + ii))) sv += -1e9f;
+            if (kmask || (causal && j > (i0 + ii) + causal - 1)) sv += -1e9f;
             const float p = __expf(sv - sL[ii]);
             const float ds = p * (dp - sD[ii]) * scale;
 #pragma unroll

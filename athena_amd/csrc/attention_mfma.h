@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
                 if constexpr (CAUSAL) {
                     // a key that is both padded and ahead of the query gets the additive mask once
                     const int kj = j0 + 16 * jt + 4 * g + r;
-                    bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
+                    bias = (kj > qi + causal - 1 && bias == 0.f) ? -1e9f : bias;
                 }
                 const float sv = s[jt][r] * scale + bias;
                 s[jt][r] = sv;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
                 float bias = kb4[r];
                 if constexpr (CAUSAL) {
                     const int kj = j0 + 16 * jt + 4 * g + r;
-                    bias = (kj > qi && bias == 0.f) ? -1e9f : bias;
+                    bias = (kj > qi + causal - 1 && bias == 0.f) ? -1e9f : bias;
                 }
                 const float sv = s[jt][r] * scale + bias;
                 const float p = __expf(sv - lse_i);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = i0 + 16 * it + 4 * g + r;
-                const float sv = s[it][r] * scale + ((kmask || (CAUSAL && kj > qi)) ? -1e9f : 0.f);
+                const float sv = s[it][r] * scale + ((kmask || (CAUSAL && kj > qi + causal - 1)) ? -1e9f : 0.f);
                 const float p = __expf(sv - lv[r]);
                 s[it][r] = p;
                 dp[it][r] = p * (dp[it][r] - dl[r]) * scale;    // dS

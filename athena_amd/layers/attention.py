@@ -8,7 +8,7 @@ from .commons import Dense
 
 class AttnMask:
     """Mask of an attention call: ``key_mask`` uint8 [B, Tk] (1 = masked key) and ``causal``
-    (key j > query i masked).  Equivalent to the reference's float masks [B,1,1,Tk] and
+    (key j > query i masked; the kernels take it as a band width, see ``MultiHeadAttention.band``).  Equivalent to the reference's float masks [B,1,1,Tk] and
     [B,1,Tq,Tk] = max(key padding, look-ahead) (athena/utils/misc.py:68-90); the kernels add the
     reference's ``mask * -1e9`` to the scaled scores."""
 
@@ -33,8 +33,11 @@ class MultiHeadAttention(nn.Module):
     def __init__(self, store, name, d_model, num_heads, unidirectional=False, look_ahead=0):
         super().__init__()
         assert d_model % num_heads == 0
-        if unidirectional:
-            raise NotImplementedError("unidirectional attention (band mask, attention.py:55-58) is not built")
+        if look_ahead < 0:
+            raise ValueError("look_ahead must be >= 0")
+        # band of a unidirectional layer (attention.py:55-58): query i sees keys j <= i + look_ahead;
+        # stored as look_ahead + 1 so that 0 means "no band"
+        self.band = int(look_ahead) + 1 if unidirectional else 0
         self.store, self.d_model, self.num_heads = store, d_model, num_heads
         self.depth = d_model // num_heads
         init = truncated_normal(0.02)
@@ -61,6 +64,8 @@ class MultiHeadAttention(nn.Module):
             raise NotImplementedError("MultiHeadAttention: k and v must be the same tensor")
         m = AttnMask.coerce(mask)
         self.store.refresh_shadows()
-        out = MultiHeadAttentionFn.apply(q.contiguous(), k.contiguous(), self, m.key_mask, m.causal,
+        # a look-ahead mask (band 1) and the layer's own band: the narrower one decides
+        band = 1 if m.causal else self.band
+        out = MultiHeadAttentionFn.apply(q.contiguous(), k.contiguous(), self, m.key_mask, band,
                                          *self.parameters())
         return out, None

@@ -253,13 +253,13 @@ def _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng):
             ffn_bwd(df, t["y1"], M, layer, (t["hpre"], t["h"]), p, rng, d_y1)
             dx, da = ops.add_layernorm_bwd(d_y1, t["z1"], t["mean1"], t["rstd1"], layer.norm1.gamma, p, rng,
                                            layer.site_res1, layer.norm1.gamma.grad, layer.norm1.beta.grad)
-            mha_block_bwd(da, x2, x2, attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
+            mha_block_bwd(da, x2, x2, attn, s_att, B, T, T, key_mask, attn.band, dx, True, dx, True)
             return dx
         df, dh, da, dx, dctx = r
         lin_bwd_w(t["h"], df, M, layer.ffn1, dff, d)
         lin_bwd_w(t["y1"], dh, M, layer.ffn0, d, dff)
         lin_bwd_w(s_att[3], da, M, attn.dense, d, d)
-        mha_block_bwd(None, x2, x2, attn, s_att, B, T, T, key_mask, False, dx, True, dx, True, dctx=dctx)
+        mha_block_bwd(None, x2, x2, attn, s_att, B, T, T, key_mask, attn.band, dx, True, dx, True, dctx=dctx)
     return dx
 
 
@@ -277,14 +277,14 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.tail = None
         if ops.layer_tail_ok(x2, d, layer.self_attn.dense, layer.ffn0, layer.ffn1):
             # everything after the attention kernel in one launch
-            c, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, False, project=False)
+            c, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, layer.self_attn.band, project=False)
             t = ops.layer_tail_fwd(c, x2.contiguous(), layer.self_attn.dense, layer.norm1, layer.ffn0, layer.ffn1,
                                    layer.norm2, LN_EPS, p, rng, layer.site_res1, layer.site_ffn_h, layer.site_res2)
             y2 = t.pop("y2")
             ctx.tail = t
             ctx.saved = (x2, s_att)
             return y2.view(B, T, d)
-        a, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, False)
+        a, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, layer.self_attn.band)
         z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(x2, a, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
                                                      layer.site_res1)
         f, s_ffn = ffn_fwd(y1, M, layer, p, rng)
@@ -314,7 +314,7 @@ class EncoderLayerFn(torch.autograd.Function):
             ffn_bwd(df, y1, M, layer, s_ffn, p, rng, d_y1)
             dx, da = ops.add_layernorm_bwd(d_y1, z1, mean1, rstd1, layer.norm1.gamma, p, rng, layer.site_res1,
                                            layer.norm1.gamma.grad, layer.norm1.beta.grad)
-            mha_block_bwd(da, x2, x2, layer.self_attn, s_att, B, T, T, key_mask, False, dx, True, dx, True)
+            mha_block_bwd(da, x2, x2, layer.self_attn, s_att, B, T, T, key_mask, layer.self_attn.band, dx, True, dx, True)
         return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 

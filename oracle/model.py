@@ -85,10 +85,11 @@ def dense(x, p, name):
     return x @ p[name + ".kernel"] + p[name + ".bias"]
 
 
-def multi_head_attention(p, name, v_in, k_in, q_in, mask, num_heads):
+def multi_head_attention(p, name, v_in, k_in, q_in, mask, num_heads, unidirectional=False, look_ahead=0):
     """MultiHeadAttention.call(v, k, q, mask) (reference athena/layers/attention.py:147-171)
     with ScaledDotProductAttention (attention.py:47-70).  ``mask`` is float, 1.0 = masked,
-    broadcastable to [B, h, Tq, Tk]."""
+    broadcastable to [B, h, Tq, Tk].  ``unidirectional`` adds (1 - band_part(ones, -1, look_ahead))
+    * -1e9 first (attention.py:55-58)."""
     B = q_in.shape[0]
     d = p[name + ".wq.kernel"].shape[1]
     depth = d // num_heads
@@ -100,6 +101,9 @@ def multi_head_attention(p, name, v_in, k_in, q_in, mask, num_heads):
     k = split(dense(k_in, p, name + ".wk"))
     v = split(dense(v_in, p, name + ".wv"))
     logits = q @ k.transpose(-1, -2) / math.sqrt(depth)
+    if unidirectional:
+        band = torch.tril(torch.ones(logits.shape[-2:], dtype=logits.dtype), diagonal=look_ahead)
+        logits = logits + (1 - band) * -1e9
     if mask is not None:
         logits = logits + mask * -1e9
     w = torch.softmax(logits, dim=-1)
@@ -117,7 +121,8 @@ def ffn(p, name, x, rate, training):
 
 def encoder_layer(p, name, src, src_mask, cfg, training):
     """TransformerEncoderLayer.call (reference athena/layers/transformer.py:296-310)."""
-    a, _ = multi_head_attention(p, name + ".self_attn", src, src, src, src_mask, cfg["num_heads"])
+    a, _ = multi_head_attention(p, name + ".self_attn", src, src, src, src_mask, cfg["num_heads"],
+                                cfg.get("unidirectional", False), cfg.get("look_ahead", 0))
     out = layer_norm(src + F.dropout(a, cfg["rate"], training),
                      p[name + ".norm1.gamma"], p[name + ".norm1.beta"])
     out = layer_norm(out + ffn(p, name + ".ffn", out, cfg["rate"], training),

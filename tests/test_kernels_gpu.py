@@ -231,7 +231,8 @@ def _attn_ref(q, k, v, key_mask, causal, scale):
     if key_mask is not None:
         mask = torch.maximum(mask, key_mask.to(q.dtype)[:, None, None, :])
     if causal:
-        mask = torch.maximum(mask, 1 - torch.tril(torch.ones(Tq, Tk, dtype=q.dtype)))
+        # True / 1: the look-ahead mask; c > 1: the band of a unidirectional layer with look_ahead = c - 1
+        mask = torch.maximum(mask, 1 - torch.tril(torch.ones(Tq, Tk, dtype=q.dtype), diagonal=int(causal) - 1))
     logits = logits + mask * -1e9
     w = torch.softmax(logits, -1)
     return (w @ vh).permute(0, 2, 1, 3)
@@ -246,7 +247,9 @@ def _attn_ref(q, k, v, key_mask, causal, scale):
                                                 # LibriSpeech-long: 750 frames after the front end, 8 heads of 64;
                                                 # decoder cross-attention of 151 label positions over them
                                                 (2, 8, 750, 750, 64, False), (2, 8, 151, 750, 64, False),
-                                                (1, 8, 151, 151, 64, True)])
+                                                (1, 8, 151, 151, 64, True),
+                                                # unidirectional encoder layers: look_ahead 3 and 2
+                                                (2, 4, 100, 100, 64, 4), (2, 2, 37, 37, 8, 3)])
 def test_mha(ops, cd, B, h, Tq, Tk, dk, causal):
     g = torch.Generator().manual_seed(B * 100 + Tq + dk)
     d = h * dk

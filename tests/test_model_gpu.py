@@ -47,10 +47,14 @@ LIBRI_DIMS = dict(vocab=5000, feat=80, mc=model_config(512, 512, 8, 2, 1, 2048, 
 # no decoder layers and the loss is the CTC term alone (mtl_weight 0): the attention branch still produces its
 # logits and its accuracy, as in the reference (mtl_seq2seq.py:86-97), with zero gradient
 ENCODER_ONLY = dict(vocab=60, feat=20, mc=model_config(64, 32, 2, 3, 0, 128, mtl_weight=0.0), B=3, T=90, U=8)
+# unidirectional encoder: every frame sees the past and two frames ahead (attention.py:55-58)
+UNIDIRECTIONAL = dict(vocab=30, feat=20, mc=model_config(64, 32, 2, 2, 1, 128, unidirectional=True, look_ahead=2),
+                      B=3, T=61, U=6)
 
 
-@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS, ENCODER_ONLY],
-                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims", "encoder-only"])
+@pytest.mark.parametrize("case", [TINY, SMALL, TIMIT_DIMS, AISHELL_DIMS, LIBRI_DIMS, ENCODER_ONLY, UNIDIRECTIONAL],
+                         ids=["tiny", "small", "timit-dims", "aishell-dims", "librispeech-dims", "encoder-only",
+                              "unidirectional"])
 def test_fp32_forward_loss_backward(case):
     model, samples, ocfg = build(case, "fp32")
     p = oracle_params(model)
