@@ -2,9 +2,10 @@
 
 The public names mirror the reference's ``athena/__init__.py:50-87`` for this path.
 """
-from .loss import CTCLoss, Seq2SeqSparseCategoricalCrossentropy
+from .loss import CTCLoss, MPCLoss, Seq2SeqSparseCategoricalCrossentropy
 from .metrics import Accuracy, CharactorAccuracy, CTCAccuracy, Seq2SeqSparseCategoricalAccuracy
 from .models.base import BaseModel
+from .models.masked_pc import MaskedPredictCoding
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
 from .solver import BaseSolver, HorovodSolver
@@ -16,7 +17,7 @@ from .utils.misc import (create_multihead_mask, generate_square_subsequent_mask,
                          insert_sos_in_labels, validate_seqs)
 
 __all__ = [
-    "CTCLoss", "Seq2SeqSparseCategoricalCrossentropy", "Accuracy", "CharactorAccuracy", "CTCAccuracy",
+    "CTCLoss", "MPCLoss", "MaskedPredictCoding", "Seq2SeqSparseCategoricalCrossentropy", "Accuracy", "CharactorAccuracy", "CTCAccuracy",
     "Seq2SeqSparseCategoricalAccuracy", "BaseModel", "MtlTransformerCtc", "SpeechTransformer", "BaseSolver",
     "HorovodSolver", "HParams", "register_and_parse_hparams", "ExponentialDecayAdam", "WarmUpAdam",
     "WarmUpLearningSchedule", "MetricChecker", "set_default_summary_writer", "create_multihead_mask",

@@ -97,6 +97,8 @@ _SIGNATURES = {
     "athena_add_layernorm_bwd_slabs": (c_int, [c_int, c_int]),
     "athena_prepare_labels": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _S]),
     "athena_ln_fold_batched": (c_int, [_P, c_int, c_int, _S]),
+    "athena_mpc_loss_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _S]),
+    "athena_mpc_loss_bwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_float, _P, c_int, _S]),
     "athena_layer_tail_workgroups": (c_int, [c_int]),
     "athena_layer_tail_fwd": (c_int, [POINTER(LayerTailFwd), _S]),
     "athena_layer_tail_bwd": (c_int, [POINTER(LayerTailBwd), _S]),

@@ -1079,6 +1079,79 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = s * scale;
 }
 
+// ---------------------------------------------------------------- MPC loss (masked L1)
+// row_loss[b, t] = sum_c |target - logit| over the elements whose (masked) input is exactly 0, for
+// frames t < logit_len[b]; one workgroup per row.
+__global__ __launch_bounds__(256) void mpc_loss_fwd_kernel(const float* __restrict__ logits, int ldl,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ masked,
+                                                          const int32_t* __restrict__ logit_len, int Tp, int N,
+                                                          float* __restrict__ row_loss) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int b = (int)(row / Tp), t = (int)(row % Tp);
+    float s = 0.f;
+    if (t < logit_len[b]) {
+        for (int c = threadIdx.x; c < N; c += 256)
+            if (masked[row * N + c] == 0.f) s += fabsf(target[row * N + c] - logits[row * ldl + c]);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) row_loss[row] = s;
+}
+
+// grad = d(sum of row losses)/dlogits * gscale[0] * host_scale: -sign(target - logit) where the
+// element counts, 0 elsewhere (also in the padding columns N .. ldl - 1)
+template <typename TG>
+__global__ __launch_bounds__(256) void mpc_loss_bwd_kernel(const float* __restrict__ logits, int ldl,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ masked,
+                                                          const int32_t* __restrict__ logit_len, int Tp, int N,
+                                                          const float* __restrict__ gscale, float host_scale,
+                                                          TG* __restrict__ grad) {
+    const long row = blockIdx.x;
+    const int b = (int)(row / Tp), t = (int)(row % Tp);
+    const bool live = t < logit_len[b];
+    const float g = gscale[0] * host_scale;
+    for (int c = threadIdx.x; c < ldl; c += 256) {
+        float v = 0.f;
+        if (live && c < N && masked[row * N + c] == 0.f) {
+            const float d = target[row * N + c] - logits[row * ldl + c];
+            v = d > 0.f ? -g : (d < 0.f ? g : 0.f);
+        }
+        grad[row * ldl + c] = from_f32<TG>(v);
+    }
+}
+
+extern "C" int athena_mpc_loss_fwd(const float* logits, int ldl, const float* target, const float* masked_input,
+                                   const int32_t* logit_len, int B, int Tp, int N, float* row_loss,
+                                   athena_stream_t stream) {
+    ATHENA_REQUIRE(logits && target && masked_input && logit_len && row_loss, ATHENA_E_SHAPE, "athena_mpc_loss_fwd: null operand");
+    ATHENA_REQUIRE(B > 0 && Tp > 0 && N > 0 && ldl >= N && (long)B * Tp < (1L << 31), ATHENA_E_SHAPE,
+                   "athena_mpc_loss_fwd: bad shape B=%d Tp=%d N=%d ldl=%d", B, Tp, N, ldl);
+    hipLaunchKernelGGL(mpc_loss_fwd_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+                       masked_input, logit_len, Tp, N, row_loss);
+    ATHENA_CHECK_LAUNCH("athena_mpc_loss_fwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_mpc_loss_bwd(const float* logits, int ldl, const float* target, const float* masked_input,
+                                   const int32_t* logit_len, int B, int Tp, int N, const float* grad_scale,
+                                   float host_scale, void* grad, int grad_dtype, athena_stream_t stream) {
+    ATHENA_REQUIRE(logits && target && masked_input && logit_len && grad_scale && grad, ATHENA_E_SHAPE, "athena_mpc_loss_bwd: null operand");
+    ATHENA_REQUIRE(B > 0 && Tp > 0 && N > 0 && ldl >= N && (long)B * Tp < (1L << 31), ATHENA_E_SHAPE,
+                   "athena_mpc_loss_bwd: bad shape B=%d Tp=%d N=%d ldl=%d", B, Tp, N, ldl);
+    if (grad_dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(mpc_loss_bwd_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+                           masked_input, logit_len, Tp, N, grad_scale, host_scale, (bf16_t*)grad);
+    else if (grad_dtype == ATHENA_F32)
+        hipLaunchKernelGGL(mpc_loss_bwd_kernel<float>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+                           masked_input, logit_len, Tp, N, grad_scale, host_scale, (float*)grad);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_mpc_loss_bwd: grad dtype");
+    ATHENA_CHECK_LAUNCH("athena_mpc_loss_bwd");
+    return ATHENA_OK;
+}
+
 extern "C" int athena_group_sum(const float* x, int ngroups, int group, float scale, float* out,
                                 athena_stream_t stream) {
     ATHENA_REQUIRE(x && out && ngroups > 0 && group > 0, ATHENA_E_SHAPE, "athena_group_sum: bad arguments");

@@ -148,3 +148,46 @@ class Seq2SeqSparseCategoricalCrossentropy:
         mode = "by_token" if self.by_token else ("by_sequence" if self.by_sequence else "mean")
         return _CELossFn.apply(logits, labels, float(self.smoothing_rate), mode,
                                ops.bf16_grad_wanted(logits))
+
+
+class _MPCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, masked, logit_len):
+        B, Tp, N = logits.shape
+        src, ldl = _as_padded_rows(logits.to(torch.float32))
+        target = target.to(torch.float32).contiguous()
+        masked = masked.to(torch.float32).contiguous()
+        logit_len = logit_len.to(torch.int32).contiguous()
+        row_loss = torch.empty(B * Tp, dtype=torch.float32, device=logits.device)
+        ops.mpc_loss_fwd(src, ldl, target, masked, logit_len, B, Tp, N, row_loss)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ops.group_sum(row_loss, 1, B * Tp, 1.0 / (B * Tp), out)
+        ctx.saved = (src, ldl, target, masked, logit_len)
+        ctx.dims = (B, Tp, N)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, ldl, target, masked, logit_len = ctx.saved
+        B, Tp, N = ctx.dims
+        gs = gout.to(torch.float32).reshape(1).contiguous()
+        grad = torch.empty((B, Tp, ldl), dtype=torch.float32, device=src.device)
+        ops.mpc_loss_bwd(src, ldl, target, masked, logit_len, B, Tp, N, gs, 1.0 / (B * Tp), grad)
+        return grad[..., :N], None, None, None
+
+
+class MPCLoss:
+    """L1 loss on the masked acoustic features of a batch (reference athena/loss.py:83-105):
+    |target - logits| where the model's input was masked to 0 and the frame is inside the utterance,
+    summed over the feature axis, averaged over all (batch, frame) positions."""
+
+    def __init__(self, name="MPCLoss"):
+        self.name = name
+
+    def __call__(self, logits, samples, logit_length=None):
+        B, Tp, N = logits.shape
+        target, masked = samples["output"], samples["input"]
+        if target.numel() != B * Tp * N or masked.numel() != B * Tp * N:
+            raise ValueError("MPCLoss: output %s / input %s do not reshape to the logits %s" %
+                             (tuple(target.shape), tuple(masked.shape), tuple(logits.shape)))
+        return _MPCLossFn.apply(logits, target, masked, logit_length)

@@ -15,6 +15,7 @@ import sys
 import torch
 
 from .data import SyntheticSpeechRecognitionDatasetBuilder
+from .models.masked_pc import MaskedPredictCoding
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
 from .solver import BaseSolver
@@ -40,6 +41,7 @@ SUPPORTED_DATASET_BUILDER = {
 SUPPORTED_MODEL = {
     "speech_transformer": SpeechTransformer,
     "mtl_transformer_ctc": MtlTransformerCtc,
+    "mpc": MaskedPredictCoding,
 }
 
 SUPPORTED_OPTIMIZER = {

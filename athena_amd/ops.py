@@ -648,6 +648,27 @@ def ce_loss_bwd(logits, ldl, targets, rows, V, ls, lse, grad_scale, host_scale, 
                "athena_ce_loss_bwd")
 
 
+def mpc_loss_fwd(logits, ldl, target, masked, logit_len, B, Tp, N, row_loss):
+    lib = _lib.load()
+    for t_ in (logits, target, masked, row_loss):
+        if t_.dtype != torch.float32:
+            raise TypeError("athena_amd.mpc_loss: fp32 tensors expected")
+    if target.numel() < B * Tp * N or masked.numel() < B * Tp * N or _extent(logits) < (B * Tp - 1) * ldl + N or \
+            logit_len.dtype != torch.int32 or logit_len.numel() < B or row_loss.numel() < B * Tp:
+        raise RuntimeError("athena_amd.mpc_loss_fwd: operand too small for B=%d Tp=%d N=%d" % (B, Tp, N))
+    _lib.check(lib.athena_mpc_loss_fwd(_ptr(logits), ldl, _ptr(target), _ptr(masked), _ptr(logit_len), B, Tp, N,
+                                       _ptr(row_loss), _stream()), "athena_mpc_loss_fwd")
+
+
+def mpc_loss_bwd(logits, ldl, target, masked, logit_len, B, Tp, N, grad_scale, host_scale, grad):
+    lib = _lib.load()
+    if grad.numel() < B * Tp * ldl or grad_scale.dtype != torch.float32:
+        raise RuntimeError("athena_amd.mpc_loss_bwd: bad operands")
+    _lib.check(lib.athena_mpc_loss_bwd(_ptr(logits), ldl, _ptr(target), _ptr(masked), _ptr(logit_len), B, Tp, N,
+                                       _ptr(grad_scale), host_scale, _ptr(grad), dt(grad), _stream()),
+               "athena_mpc_loss_bwd")
+
+
 def group_sum(x, ngroups, group, scale, out):
     lib = _lib.load()
     if x.dtype != torch.float32 or out.dtype != torch.float32 or x.numel() < ngroups * group:

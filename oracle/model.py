@@ -240,6 +240,26 @@ def forward(p, samples, cfg, training=True, bn_stats_out=None):
     return att_logits, ctc_logits, mem
 
 
+def mpc_forward(p, samples, cfg, training=True, bn_stats_out=None):
+    """MaskedPredictCoding.call (reference athena/models/masked_pc.py:122-136): x_net, the encoder
+    stack without any mask, Dense(4 * feature size)."""
+    x = x_net(p, samples["input"], cfg, training, bn_stats_out)
+    for i in range(cfg["num_encoder_layers"]):
+        x = encoder_layer(p, "encoder.%d" % i, x, None, cfg, training)
+    return dense(x, p, "final_layer")
+
+
+def mpc_loss(logits, samples, logit_length):
+    """MPCLoss.__call__ (reference athena/loss.py:91-105)."""
+    shape = logits.shape
+    target = samples["output"].reshape(shape).to(logits.dtype)
+    loss = target - logits
+    loss = loss * (samples["input"].reshape(shape) == 0).to(loss.dtype)
+    seq_mask = (torch.arange(shape[1])[None, :] < logit_length[:, None]).to(loss.dtype)
+    loss = loss * seq_mask[:, :, None]
+    return loss.abs().sum(-1).mean()
+
+
 # ----------------------------------------------------------------------------
 # losses (reference athena/loss.py:24-80)
 # ----------------------------------------------------------------------------

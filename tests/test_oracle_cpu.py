@@ -210,3 +210,30 @@ def test_train_step_decreases_loss_and_is_deterministic():
     assert runs[0] == runs[1]
     assert runs[0][-1] < runs[0][1]          # (step 0 has lr 0: losses[0] == losses[1])
     assert abs(runs[0][0] - runs[0][1]) < 1e-12
+
+
+def test_mpc_loss_oracle_against_explicit_loops():
+    """oracle.model.mpc_loss (reference athena/loss.py:91-105) against the definition written out:
+    sum over features of |target - output| where the input is 0 and the frame is inside the
+    utterance, averaged over all batch x frame positions (padded ones included in the count)."""
+    from oracle import model as om
+    g = torch.Generator().manual_seed(3)
+    B, Tp, N = 2, 5, 6
+    logits = torch.randn(B, Tp, N, generator=g, dtype=torch.float64)
+    target = torch.randn(B, Tp, N, generator=g, dtype=torch.float64)
+    masked = target.clone()
+    masked[0, 1] = 0.0
+    masked[1, 0] = 0.0
+    masked[1, 4] = 0.0          # beyond the utterance: not counted
+    masked[0, 3, 2] = 0.0       # a single feature that happens to be 0 counts as well
+    length = torch.tensor([5, 3])
+    total = 0.0
+    for b in range(B):
+        for t in range(Tp):
+            if t >= int(length[b]):
+                continue
+            for c in range(N):
+                if float(masked[b, t, c]) == 0.0:
+                    total += abs(float(target[b, t, c]) - float(logits[b, t, c]))
+    got = om.mpc_loss(logits, {"output": target.reshape(B, Tp * 2, 3), "input": masked.reshape(B, Tp * 2, 3, 1)}, length)
+    assert abs(float(got) - total / (B * Tp)) < 1e-12
