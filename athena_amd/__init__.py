@@ -8,7 +8,9 @@ from .models.base import BaseModel
 from .models.masked_pc import MaskedPredictCoding
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
-from .solver import BaseSolver, HorovodSolver
+from .solver import BaseSolver, DecoderSolver, HorovodSolver
+from .tools.beam_search import BeamSearchDecoder
+from .tools.ctc_scorer import CTCPrefixScorer
 from .utils.checkpoint import Checkpoint
 from .utils.hparam import HParams, register_and_parse_hparams
 from .utils.learning_rate import ExponentialDecayAdam, WarmUpAdam, WarmUpLearningSchedule
@@ -19,7 +21,7 @@ from .utils.misc import (create_multihead_mask, generate_square_subsequent_mask,
 __all__ = [
     "CTCLoss", "MPCLoss", "MaskedPredictCoding", "Seq2SeqSparseCategoricalCrossentropy", "Accuracy", "CharactorAccuracy", "CTCAccuracy",
     "Seq2SeqSparseCategoricalAccuracy", "BaseModel", "MtlTransformerCtc", "SpeechTransformer", "BaseSolver",
-    "HorovodSolver", "HParams", "register_and_parse_hparams", "ExponentialDecayAdam", "WarmUpAdam",
+    "HorovodSolver", "DecoderSolver", "BeamSearchDecoder", "CTCPrefixScorer", "HParams", "register_and_parse_hparams", "ExponentialDecayAdam", "WarmUpAdam",
     "WarmUpLearningSchedule", "MetricChecker", "set_default_summary_writer", "create_multihead_mask",
     "generate_square_subsequent_mask", "insert_eos_in_labels", "insert_sos_in_labels", "validate_seqs",
     "Checkpoint",

@@ -96,4 +96,18 @@ class MtlTransformerCtc(BaseModel):
         self.model.restore_from_pretrained_model(pretrained_model, model_type)
 
     def decode(self, samples, hparams, decoder):
-        raise NotImplementedError("decoding (mtl_seq2seq.py:117-156) is outside the built training path")
+        """Joint attention / CTC decoding of one utterance (mtl_seq2seq.py:117-156): the encoder output
+        feeds the attention decoder inside ``decoder`` and -- with a CTC weight -- the CTC head, whose
+        log-probabilities initialise the prefix scorer."""
+        encoder_output, input_mask = self.model.decode(samples, hparams, decoder, return_encoder=True)
+        history_predictions = torch.full((1, 1), self.sos, dtype=torch.int64)
+        init_cand_states = [history_predictions]
+        if hparams.decoder_type == "beam_search_decoder":
+            if hparams.ctc_weight != 0 and decoder.ctc_scorer is not None:
+                with torch.no_grad():
+                    ctc_logits = SpeechTransformer._project(self.decoder, encoder_output).to(torch.float32)
+                    ctc_logits = torch.log_softmax(ctc_logits, dim=-1)
+                init_cand_states = decoder.ctc_scorer.initial_state(init_cand_states, ctc_logits)
+            return decoder(history_predictions, init_cand_states, 0, (encoder_output, input_mask))
+        raise NotImplementedError("decoder_type %r: only beam_search_decoder is built (the WFST decoder is not)"
+                                  % (hparams.decoder_type,))

@@ -183,7 +183,41 @@ class SpeechTransformer(BaseModel):
             raise ValueError("NOT SUPPORTED")
 
     def time_propagate(self, history_logits, history_predictions, step, enc_outputs):
-        raise NotImplementedError("decoding (speech_transformer.py:164-238) is outside the built training path")
+        """One decoding step for every live hypothesis (speech_transformer.py:164-194): the decoder
+        runs over the whole history ``history_predictions`` [n, step + 1] (int, <sos> first) and the
+        logits of the newest position come back.  Returns (logits [n, num_class] fp32,
+        history_logits + [logits], step + 1)."""
+        encoder_output, memory_mask = enc_outputs
+        if isinstance(history_predictions, (list, tuple)):
+            history_predictions = torch.stack([torch.as_tensor(t) for t in history_predictions], dim=1)
+        y0 = torch.as_tensor(history_predictions).to(device=self.store.device, dtype=torch.int32).contiguous()
+        n = y0.shape[0]
+        memory = encoder_output
+        if memory.shape[0] != n:
+            memory = memory[:1].expand(n, -1, -1)
+        memory = memory.contiguous()
+        mm = AttnMask.coerce(memory_mask)
+        if mm.key_mask is not None and mm.key_mask.shape[0] != n:
+            mm = AttnMask(mm.key_mask[:1].expand(n, -1).contiguous(), False)
+        with torch.no_grad():
+            self.store.refresh_shadows()
+            y = self.y_net(y0, training=False)
+            y = self.transformer.decoder(y, memory, tgt_mask=AttnMask(None, True), memory_mask=mm, training=False)
+            logits = self._project(self.final_layer, y)[:, -1, :].to(torch.float32)
+        return logits, list(history_logits) + [logits], step + 1
 
     def decode(self, samples, hparams, decoder, return_encoder=False):
-        raise NotImplementedError("decoding (speech_transformer.py:196-238) is outside the built training path")
+        """Beam-search decoding of a batch of one utterance (speech_transformer.py:196-238): the
+        encoder runs once in inference mode; with ``return_encoder`` its output and the input mask
+        are returned, otherwise ``decoder`` searches from <sos> and its predictions come back."""
+        with torch.no_grad():
+            self.store.refresh_shadows()
+            x = self.x_net(samples["input"], training=False)
+            input_length = self.compute_logit_length(samples)
+            input_mask, _ = create_multihead_mask(x, input_length, None)
+            encoder_output = self.transformer.encoder(x, input_mask, training=False)
+        if return_encoder:
+            return encoder_output, input_mask
+        batch = samples["input"].shape[0]
+        history_predictions = torch.full((batch, 1), self.sos, dtype=torch.int64)
+        return decoder(history_predictions, [history_predictions], 0, (encoder_output, input_mask))

@@ -478,3 +478,58 @@ class HorovodSolver(BaseSolver):
                 if self.rank == 0:
                     logging.info(self.metric_checker(loss, metrics))
                 self.model.reset_metrics()
+
+
+class DecoderSolver(BaseSolver):
+    """Decoding driver (reference athena/solver.py:221-283): builds the beam-search decoder around the
+    model's ``time_propagate`` and scores the predictions of a data set with the character accuracy."""
+    default_config = {
+        "inference_type": "asr",
+        "decoder_type": "wfst_decoder",
+        "model_avg_num": 1,
+        "beam_size": 4,
+        "ctc_weight": 0.0,
+        "lm_weight": 0.1,
+        "lm_type": "",
+        "lm_path": None,
+        "acoustic_scale": 10.0,
+        "max_active": 80,
+        "min_active": 0,
+        "wfst_beam": 30.0,
+        "max_seq_len": 100,
+        "wfst_graph": None
+    }
+
+    def __init__(self, model, data_descriptions=None, config=None):
+        from .tools.beam_search import BeamSearchDecoder
+        from .utils.hparam import register_and_parse_hparams
+        self.model = model
+        self.optimizer = None
+        self.hparams = register_and_parse_hparams(self.default_config, config, cls=self.__class__)
+        if self.hparams.decoder_type == "beam_search_decoder":
+            self.decoder = BeamSearchDecoder.build_decoder(self.hparams, model.num_class, model.sos, model.eos,
+                                                           model.time_propagate)
+        elif self.hparams.decoder_type == "wfst_decoder":
+            raise NotImplementedError("the WFST decoder (athena/tools/wfst_decoder.py) is not built")
+        else:
+            raise ValueError("This decoder type is not supported")
+
+    def inference(self, dataset, rank_size=1):
+        """decode the model: one utterance per batch; logs predictions, labels and the running accuracy"""
+        import time
+        from .metrics import CharactorAccuracy
+        from .utils.misc import validate_seqs
+        if dataset is None:
+            return None
+        metric = CharactorAccuracy(rank_size=rank_size)
+        for samples in dataset:
+            begin = time.time()
+            samples = self.model.prepare_samples(samples)
+            predictions = self.model.decode(samples, self.hparams, self.decoder)
+            validated = validate_seqs(predictions, self.model.eos)[0]
+            num_errs, _ = metric.update_state(validated, samples)
+            logging.info("predictions: %s\tlabels: %s\terrs: %d\tavg_acc: %.4f\tsec/iter: %.4f",
+                         predictions.tolist(), samples["output"].tolist(), num_errs, metric.result(),
+                         time.time() - begin)
+        logging.info("decoding finished")
+        return metric.result()

@@ -1,0 +1,114 @@
+"""The CTC prefix scorer and the beam search on the CPU: the product scorer (numpy, batched over the
+beam) against an enumeration of all CTC paths and against the loop restatement in oracle/decode.py;
+the search itself on a scripted "model" whose best hypotheses are known."""
+import itertools
+import math
+
+import numpy as np
+import torch
+
+from athena_amd.tools.beam_search import BeamSearchDecoder, CandidateHolder
+from athena_amd.tools.ctc_scorer import CTCPrefixScorer
+from oracle import decode as od
+
+
+def _collapse(path, blank):
+    out, prev = [], None
+    for s in path:
+        if s != prev and s != blank:
+            out.append(s)
+        prev = s
+    return out
+
+
+def _brute(x, blank, prefix, exact):
+    """log of the total probability of all frame paths whose label sequence starts with (or, with
+    ``exact``, is) ``prefix``."""
+    T, V = x.shape
+    total = 0.0
+    for path in itertools.product(range(V), repeat=T):
+        lab = _collapse(path, blank)
+        hit = lab == prefix if exact else lab[:len(prefix)] == prefix
+        if hit:
+            total += math.exp(sum(float(x[t, s]) for t, s in enumerate(path)))
+    return math.log(total) if total > 0 else -math.inf
+
+
+def test_prefix_scores_equal_path_enumeration_and_the_loop_oracle():
+    g = torch.Generator().manual_seed(4)
+    T, V = 5, 4
+    blank = eos = V - 1
+    x = torch.log_softmax(torch.randn(1, T, V, generator=g), -1)
+    scorer = CTCPrefixScorer(eos, ctc_beam=V, num_classes=V, ctc_weight=0.3)
+    states = scorer.initial_state([np.array([[eos]])], x)
+    xn = x[0].numpy()
+    # grow a hypothesis label by label; at each length score every label
+    seq = [eos]                     # <sos> shares the index with <eos> and the blank
+    r_prev = scorer.init_state
+    for step, nxt in enumerate([1, 1, 0]):
+        cs = np.arange(V)
+        psi, new_states = scorer.cand_score(np.array(seq), cs, r_prev)
+        ref_psi, ref_states = od.prefix_scores(xn, blank, eos, seq, list(cs), r_prev)
+        for c in range(V):
+            want = _brute(xn, blank, seq[1:], True) if c == eos else _brute(xn, blank, seq[1:] + [c], False)
+            assert abs(float(psi[c]) - want) < 2e-5, (step, c, float(psi[c]), want)
+            assert abs(float(psi[c]) - float(ref_psi[c])) < 1e-6
+            lo = max(len(seq) - 1, 1) - 1
+            assert np.allclose(new_states[c][lo:], np.array(ref_states[c], dtype=np.float32)[lo:], atol=1e-6)
+        seq = seq + [nxt]
+        r_prev = new_states[nxt]
+
+
+def test_score_adds_weighted_differences_for_the_ctc_beam_and_minus_500_elsewhere():
+    g = torch.Generator().manual_seed(7)
+    T, V = 6, 6
+    eos = V - 1
+    x = torch.log_softmax(torch.randn(1, T, V, generator=g), -1)
+    scorer = CTCPrefixScorer(eos, ctc_beam=3, num_classes=V, ctc_weight=0.5)
+    states = scorer.initial_state([np.array([[eos]])], x)
+    holder = CandidateHolder(np.array([[eos]]), [], states, np.zeros(1, np.float32), np.zeros(1, np.int64))
+    att = np.log(np.array([[0.05, 0.4, 0.05, 0.3, 0.05, 0.15]], dtype=np.float32))
+    add, states = scorer.score(holder, att)
+    top = [1, 3, 5]
+    psi, _ = scorer.cand_score(np.array([eos]), np.array(top), scorer.init_state)
+    for c in range(V):
+        if c in top:
+            assert abs(float(add[0, c]) - 0.5 * float(psi[top.index(c)])) < 1e-4
+        else:
+            assert float(add[0, c]) == -500.0
+    # second step from label 3: the differences are taken against the total stored for it
+    holder = CandidateHolder(np.array([[eos, 3]]), [], [np.array([[eos, 3]])] + states[1:], np.zeros(1, np.float32),
+                             np.zeros(1, np.int64))
+    add2, _ = scorer.score(holder, att)
+    psi2, _ = scorer.cand_score(np.array([eos, 3]), np.array(top), states[scorer.state_index].states[0, 1])
+    assert abs(float(add2[0, 1]) - 0.5 * (float(psi2[0]) - float(psi[1]))) < 1e-4
+
+
+class _Scripted:
+    """A decoder step whose logits depend on the last label only (a first-order chain)."""
+
+    def __init__(self, table):
+        self.table = torch.tensor(table, dtype=torch.float32)
+
+    def __call__(self, history_logits, seqs, step, enc):
+        seqs = torch.as_tensor(np.asarray(seqs))
+        logits = self.table[seqs[:, -1]]
+        return logits, list(history_logits) + [logits], step + 1
+
+
+def test_beam_search_finds_the_best_chain_and_beam_one_is_greedy():
+    # classes 0, 1, 2 and <sos>/<eos> = 3; greedy goes 0 -> eos (0.6 * 0.5), the best path is 1 -> 2 -> eos
+    P = np.array([[0.05, 0.05, 0.4, 0.5],       # after 0
+                  [0.02, 0.02, 0.94, 0.02],     # after 1
+                  [0.02, 0.02, 0.02, 0.94],     # after 2
+                  [0.6, 0.4, 0.0001, 0.0001]])  # after <sos>
+    step = _Scripted(np.log(P / P.sum(1, keepdims=True)))
+    enc = (torch.zeros(1, 8, 4), None)
+
+    class HP:
+        decoder_type, beam_size, ctc_weight, lm_weight = "beam_search_decoder", 3, 0.0, 0.0
+    out = BeamSearchDecoder.build_decoder(HP, 4, 3, 3, step)(torch.tensor([[3]]), [torch.tensor([[3]])], 0, enc)
+    assert out.tolist() == [[1, 2, 3]]
+    HP.beam_size = 1
+    out = BeamSearchDecoder.build_decoder(HP, 4, 3, 3, step)(torch.tensor([[3]]), [torch.tensor([[3]])], 0, enc)
+    assert out.tolist() == [[0, 3]]
