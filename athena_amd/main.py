@@ -14,7 +14,7 @@ import sys
 
 import torch
 
-from .data import SyntheticSpeechRecognitionDatasetBuilder
+from .data import SpeechRecognitionDatasetBuilder, SyntheticSpeechRecognitionDatasetBuilder
 from .models.masked_pc import MaskedPredictCoding
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
@@ -27,14 +27,15 @@ from .utils.metric_check import set_default_summary_writer
 
 def _not_built(name):
     def build(*args, **kwargs):
-        raise NotImplementedError("%r reads real corpora (csv, vocabulary, cmvn) and is not part of this package; "
-                                  "use 'synthetic_speech_recognition' or pass a builder object" % name)
+        raise NotImplementedError("%r (Kaldi ark / scp features) is not part of this package; use "
+                                  "'speech_recognition_dataset', 'synthetic_speech_recognition' or pass a builder "
+                                  "object" % name)
     return build
 
 
 SUPPORTED_DATASET_BUILDER = {
     "synthetic_speech_recognition": SyntheticSpeechRecognitionDatasetBuilder,
-    "speech_recognition_dataset": _not_built("speech_recognition_dataset"),
+    "speech_recognition_dataset": SpeechRecognitionDatasetBuilder,
     "speech_recognition_dataset_kaldiio": _not_built("speech_recognition_dataset_kaldiio"),
 }
 

@@ -1,0 +1,175 @@
+"""The CSV-indexed speech-recognition data set (reference athena/data/datasets/speech_recognition.py,
+athena/data/datasets/base.py), its text featurizers (athena/data/text_featurizer.py), CMVN
+(athena/data/feature_normalizer.py) and the filterbank front end, on the CPU.
+
+Vocabulary fixtures are data files of the reference: tests/golden/vocabs/en.vocab is its
+athena/utils/vocabs/en.vocab, aishell_head60.vocab the first 60 lines of its
+examples/asr/aishell/data/vocab.  The filterbank has no reference values to be checked against (the
+wav its unit test reads is not in the repository): its tests check the definition instead."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from athena_amd.data import (AudioFeaturizer, FeatureNormalizer, SpeechRecognitionDatasetBuilder, TextFeaturizer,
+                             Vocabulary)
+from athena_amd.data.audio_featurizer import mel_filterbank
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EN_VOCAB = os.path.join(HERE, "golden", "vocabs", "en.vocab")
+ZH_VOCAB = os.path.join(HERE, "golden", "vocabs", "aishell_head60.vocab")
+
+
+def test_vocabulary_files_of_the_reference():
+    en = Vocabulary(EN_VOCAB)
+    assert len(en) == 30 and en.unk_index == 0 or en.stoi["<unk>"] == en.unk_index
+    ids = en.encode("Hello World")
+    assert ids == [en.stoi[c] for c in "hello"] + [en.stoi["<space>"]] + [en.stoi[c] for c in "world"]
+    assert en.decode(ids) == "hello world"
+    assert en.encode("h3llo")[1] == en.unk_index            # a character outside the vocabulary
+    zh = TextFeaturizer({"type": "vocab", "model": ZH_VOCAB})
+    assert zh.unk_index == 0 and len(zh) == 60
+    assert zh.encode("一丁七") == [2, 3, 4] and zh.decode([2, 3, 4]) == "一丁七"
+    assert zh.model(3) == "丁" and zh.model([4, 2]) == "七一"
+
+
+def test_word_tokenizer_ranks_by_count_then_first_seen():
+    t = TextFeaturizer({"type": "text", "model": None})
+    t.load_model(["the cat sat", "The dog sat.", "a cat"])
+    # counts: the 2, cat 2, sat 2, dog 1, a 1 -> ids in that order
+    assert t.model.word_index == {"the": 1, "cat": 2, "sat": 3, "dog": 4, "a": 5}
+    assert len(t) == 6 and t.unk_index == -1
+    assert t.encode("A dog, the bird") == [5, 4, 1]
+    assert t.decode([1, 2]) == "the cat"
+
+
+def _write_csv(path, rows, speaker=True):
+    head = "wav_filename\twav_length_ms\ttranscript" + ("\tspeaker" if speaker else "")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(head + "\n")
+        for r in rows:
+            f.write("\t".join(str(v) for v in (r if speaker else r[:3])) + "\n")
+
+
+def _features(tmp_path, name, frames, dim=8, seed=0):
+    rng = np.random.default_rng(seed)
+    path = str(tmp_path / (name + ".npy"))
+    np.save(path, (rng.standard_normal((frames, dim)) * (1 + seed) + seed).astype(np.float32))
+    return path
+
+
+def _builder(tmp_path, rows, **extra):
+    csv = str(tmp_path / "data.csv")
+    _write_csv(csv, rows, speaker=extra.pop("speaker", True))
+    cfg = {"audio_config": {"type": "Fbank", "filterbank_channel_count": 8},
+           "text_config": {"type": "vocab", "model": EN_VOCAB}, "data_csv": csv}
+    cfg.update(extra)
+    return SpeechRecognitionDatasetBuilder(cfg)
+
+
+def test_csv_entries_are_sorted_filtered_and_permuted(tmp_path):
+    rows = [(_features(tmp_path, "a", 30), 300, "hello", "s1"),
+            (_features(tmp_path, "b", 12), 120, "hi there", "s2"),
+            (_features(tmp_path, "c", 20), 200, "caf3", "s1"),          # '3' is not in the vocabulary -> dropped
+            (_features(tmp_path, "d", 1), 10, "a", "s2"),               # shorter than input_length_range[0]
+            (_features(tmp_path, "e", 25), 250, "", "s1")]              # empty transcript
+    b = _builder(tmp_path, rows)
+    assert b.speakers == ["s1", "s2"] and b.num_class == 30
+    assert [os.path.basename(e[0]) for e in b.entries] == ["b.npy", "a.npy"]          # by duration
+    assert b.entries[0][1:] == (120.0, "hi there", 1.0, "s2")
+    # speed permutation: every utterance once per speed, durations divided by the speed, sorted together
+    b2 = _builder(tmp_path, rows[:2], speed_permutation=[0.9, 1.0, 1.1])
+    assert [round(e[1], 2) for e in b2.entries] == [109.09, 120.0, 133.33, 272.73, 300.0, 333.33]
+    assert [e[3] for e in b2.entries] == [1.1, 1.0, 0.9, 1.1, 1.0, 0.9]
+    # without a speaker column everything belongs to "global"
+    b3 = _builder(tmp_path, rows[:2], speaker=False)
+    assert b3.speakers == ["global"] and all(e[4] == "global" for e in b3.entries)
+    # remove_unk off keeps the utterance with the unknown character
+    b4 = _builder(tmp_path, rows, remove_unk=False)
+    assert "c.npy" in [os.path.basename(e[0]) for e in b4.entries]
+
+
+def test_items_batches_shard_and_shuffle(tmp_path):
+    rows = [(_features(tmp_path, "u%d" % i, 10 + 3 * i, seed=i), 100 + 30 * i, "ab" + "c" * i, "s%d" % (i % 2))
+            for i in range(7)]
+    b = _builder(tmp_path, rows)
+    item = b[2]
+    assert item["input"].shape == (16, 8, 1) and item["input_length"] == 16
+    assert item["output"] == [1, 2, 3, 3] and item["output_length"] == 4
+    assert b.sample_shape["input"] == (None, 8, 1) and b.sample_signature[0]["output"][0] == (None, None)
+    batches = b.as_dataset(batch_size=3)
+    assert len(batches) == 2                                   # 7 // 3: the incomplete batch is dropped
+    first = batches[0]
+    assert first["input"].shape == (3, 16, 8, 1) and first["output"].shape == (3, 4)
+    assert first["input_length"].tolist() == [10, 13, 16] and first["output_length"].tolist() == [2, 3, 4]
+    assert float(first["input"][0, 10:].abs().sum()) == 0.0 and first["output"][0].tolist() == [1, 2, 0, 0]
+    assert torch.equal(first["input"][1, :13], torch.from_numpy(b[1]["input"]))
+    b.shard(3, 1)
+    assert len(b) == 2 and [os.path.basename(e[0]) for e in b.entries] == ["u1.npy", "u4.npy"]
+    with pytest.raises(ValueError):
+        b.shard(2, 2)
+    b = _builder(tmp_path, rows)
+    before = list(b.entries)
+    b.batch_wise_shuffle(batch_size=3)
+    assert sorted(b.entries) == sorted(before) and b.entries[6] == before[6]
+    chunks = [b.entries[i:i + 3] for i in (0, 3)]
+    assert all(c in (before[0:3], before[3:6]) for c in chunks)
+
+
+def test_cmvn_is_computed_saved_loaded_and_applied(tmp_path):
+    rows = [(_features(tmp_path, "u%d" % i, 40 + i, seed=i), 400 + 10 * i, "abc", "s%d" % (i % 2)) for i in range(4)]
+    cmvn = str(tmp_path / "cmvn")
+    b = _builder(tmp_path, rows, cmvn_file=cmvn)
+    b.compute_cmvn_if_necessary(True)
+    assert os.path.exists(cmvn)
+    with open(cmvn, encoding="utf-8") as f:
+        head = f.readline().rstrip("\n").split("\t")
+        line = f.readline().rstrip("\n").split("\t")
+    assert head == ["speaker", "mean", "var"] and line[0] == "s0" and len(json.loads(line[1])) == 8
+    feats = [np.load(r[0]) for r in rows]
+    s0 = np.concatenate([feats[0], feats[2]])
+    assert np.allclose(b.feature_normalizer.cmvn_dict["s0"][0], s0.mean(0), atol=1e-4)
+    assert np.allclose(b.feature_normalizer.cmvn_dict["s0"][1], s0.var(0), rtol=1e-3)
+    again = FeatureNormalizer(cmvn)
+    assert np.allclose(again.cmvn_dict["s1"][0], b.feature_normalizer.cmvn_dict["s1"][0])
+    x = b[0]["input"]                                           # normalised with its speaker's statistics
+    raw = feats[0][:, :, None]
+    assert np.allclose(x, (raw - s0.mean(0)[None, :, None]) / np.sqrt(s0.var(0))[None, :, None], atol=1e-3)
+    assert np.allclose(again(x, "s0", reverse=True), raw, atol=1e-3)
+    assert again(raw, "nobody") is raw
+
+
+def test_fbank_follows_its_definition():
+    """One frame by hand: mean removal, in-frame pre-emphasis, povey window, 512-point power
+    spectrum, triangular mel bands, log."""
+    rate = 16000
+    rng = np.random.default_rng(0)
+    audio = (rng.standard_normal(16000 // 4) * 3000).astype(np.float32)
+    f = AudioFeaturizer({"type": "Fbank"})
+    out = f(audio, sr=rate)
+    assert out.shape == ((len(audio) - 400) // 160 + 1, 40, 1) and out.dtype == np.float32
+    n = 5
+    frame = audio[n * 160:n * 160 + 400].astype(np.float64)
+    frame = frame - frame.mean()
+    frame = np.concatenate([[frame[0] * (1 - 0.97)], frame[1:] - 0.97 * frame[:-1]])
+    win = np.power(0.5 - 0.5 * np.cos(2 * np.pi * np.arange(400) / 399), 0.85)
+    power = np.abs(np.fft.rfft(frame * win, 512)) ** 2
+    bank = mel_filterbank(257, rate, 40, 60, 8000.0)
+    assert np.allclose(out[n, :, 0], np.log(power @ bank), rtol=2e-4, atol=2e-4)
+    # the bands: non-negative, bins between the limits are shared between two neighbours with weights adding to 1
+    assert bank.shape == (257, 40) and float(bank.min()) >= 0.0
+    inside = bank.sum(1)[8:250]
+    # (above the last band's centre only its falling slope is left)
+    assert np.all(inside > 0) and np.all(inside <= 1.0 + 1e-12) and np.allclose(inside[5:-40], 1.0)
+    centers = bank.argmax(0)
+    assert np.all(np.diff(centers) > 0)
+    # a pure tone lands in the band around its frequency
+    t = np.arange(4000) / rate
+    tone = (10000 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    hot = int(f(tone, sr=rate)[3, :, 0].argmax())
+    lo, hi = np.nonzero(bank[:, hot])[0][[0, -1]] * (rate / 512)
+    assert lo <= 1000.0 <= hi
+    # speed 2: half as many samples
+    assert f(audio, sr=rate, speed=2.0).shape[0] == ((len(audio) // 2) - 400) // 160 + 1
