@@ -312,7 +312,9 @@ def test_main_config_defaults_and_recipes_parse():
         assert p.model == "mtl_transformer_ctc" and p.model in amain.SUPPORTED_MODEL
         assert p.batch_size == cfg["batch_size"] and p.model_config == cfg["model_config"]
     with pytest.raises(NotImplementedError):
-        amain.SUPPORTED_DATASET_BUILDER["speech_recognition_dataset"](None)
+        amain.SUPPORTED_DATASET_BUILDER["speech_recognition_dataset_kaldiio"](None)
+    from athena_amd.data import SpeechRecognitionDatasetBuilder
+    assert amain.SUPPORTED_DATASET_BUILDER["speech_recognition_dataset"] is SpeechRecognitionDatasetBuilder
 
 
 def test_synthetic_dataset_builder_batches_shards_and_shuffles():
