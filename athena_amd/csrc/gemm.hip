@@ -348,6 +348,8 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
     int Ho, Wo, ph, pw;
     same_pad(H, &Ho, &ph);
     same_pad(W, &Wo, &pw);
+    GemmProblem<ConvDgradRows> merged[4];
+    int n_merged = 0;
     // padded coordinate hp = h + pad: even hp = 2a is reached by taps kh=0 (ho=a) and kh=2 (ho=a-1),
     // odd hp = 2a+1 by tap kh=1 (ho=a)
     for (int ch = 0; ch < 2; ++ch) {
@@ -400,14 +402,17 @@ extern "C" int athena_conv3x3s2_dgrad(const void* dout, const void* w_hwio, void
             p.crow_mode = 1;
             p.cr_Ah = Ah; p.cr_Aw = Aw; p.cr_H = H; p.cr_W = W; p.cr_h0 = h0; p.cr_w0 = w0;
             if (big_tiles_enabled() && ((Cin > 128 && p.M >= 64 * GB_BM) || big_tiles_forced()) &&
-                gemm_big_ok(p, dtype, false))
-                rc = launch_gemm_big(p, false, true, (hipStream_t)stream);
-            else
-                rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,
-                                 (hipStream_t)stream);
+                gemm_big_ok(p, dtype, false)) {
+                // the parity classes that qualify for the large tile go out together below
+                merged[n_merged++] = p;
+                continue;
+            }
+            rc = launch_gemm(p, dtype, false, true, gemm_plan(p.M, p.N, (long)p.nseg * Cout, dtype, 1, false).bt,
+                             (hipStream_t)stream);
             if (rc) return rc;
         }
     }
+    if (n_merged > 0) return launch_gemm_big_multi(merged, n_merged, (hipStream_t)stream);
     return ATHENA_OK;
 }
 

@@ -418,6 +418,63 @@ static inline bool gemm_big_ok(const GemmProblem<AMap>& p, int in_dtype, bool ta
     return true;
 }
 
+// ------------------------------------------------------------------ several problems, one launch
+// Up to four problems of one row map (the four parity classes of the stride-2 convolution's input
+// gradient: 1, 2, 2 and 4 taps, each a fraction of a chip's worth of tiles) as ONE launch: the tiles
+// of the problem with the longest contraction come first, so that the short ones fill the CUs behind
+// them.  first_tile[i] .. first_tile[i + 1] - 1 are the workgroups of problem i.
+#define GB_MULTI_MAX 4
+template <class AMap>
+struct GbMulti {
+    GemmProblem<AMap> p[GB_MULTI_MAX];
+    int first_tile[GB_MULTI_MAX + 1];
+    int count;
+};
+
+template <class AMap, bool TA, bool TB>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_multi_kernel(const GbMulti<AMap> m) {
+    __shared__ __attribute__((aligned(1024))) bf16_t lds[GB_LDS_ELEMS];
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < GB_MULTI_MAX; ++q)
+        if (q < m.count && (int)blockIdx.x >= m.first_tile[q]) i = q;
+    const int local = blockIdx.x - m.first_tile[i];
+    // a uniform switch instead of m.p[i]: every problem is addressed with constant offsets
+    switch (i) {
+        case 0: { const int tm = (m.p[0].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[0], local % tm, local / tm, 0, lds); } break;
+        case 1: { const int tm = (m.p[1].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[1], local % tm, local / tm, 0, lds); } break;
+        case 2: { const int tm = (m.p[2].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[2], local % tm, local / tm, 0, lds); } break;
+        default: { const int tm = (m.p[3].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[3], local % tm, local / tm, 0, lds); } break;
+    }
+}
+
+// problems with split_k == 1, no z batch, (!ta && tb); sorted here by contraction length
+template <class AMap>
+static int launch_gemm_big_multi(const GemmProblem<AMap>* probs, int count, hipStream_t stream) {
+    if (count < 1 || count > GB_MULTI_MAX) return ATHENA_E_UNSUPPORTED;
+    int order[GB_MULTI_MAX];
+    for (int i = 0; i < count; ++i) order[i] = i;
+    for (int i = 0; i < count; ++i)
+        for (int j = i + 1; j < count; ++j)
+            if ((long)probs[order[j]].nseg * probs[order[j]].kseg > (long)probs[order[i]].nseg * probs[order[i]].kseg) {
+                const int t = order[i]; order[i] = order[j]; order[j] = t;
+            }
+    GbMulti<AMap> m;
+    memset(&m, 0, sizeof(m));
+    m.count = count;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        m.p[i] = probs[order[i]];
+        if (m.p[i].split_k != 1 || m.p[i].zbatch > 1) return ATHENA_E_UNSUPPORTED;
+        m.first_tile[i] = tiles;
+        tiles += ((m.p[i].M + GB_BM - 1) / GB_BM) * ((m.p[i].N + GB_BN - 1) / GB_BN);
+    }
+    for (int i = count; i <= GB_MULTI_MAX; ++i) m.first_tile[i] = tiles;
+    hipLaunchKernelGGL((gemm_big_multi_kernel<AMap, false, true>), dim3(tiles), dim3(GB_THREADS), 0, stream, m);
+    ATHENA_CHECK_LAUNCH("gemm(large tile, several problems)");
+    return ATHENA_OK;
+}
+
 template <class AMap>
 static int launch_gemm_big(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_t stream) {
     const int tm = (p.M + GB_BM - 1) / GB_BM, tn = (p.N + GB_BN - 1) / GB_BN;
