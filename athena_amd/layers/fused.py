@@ -353,6 +353,26 @@ class DecoderLayerFn(torch.autograd.Function):
         p = layer.rate if training else 0.0
         t2 = tgt.reshape(M, d)
         m2 = memory.reshape(B * T, d)
+        ctx.layer, ctx.masks, ctx.p, ctx.shape = layer, (tgt_key_mask, mem_key_mask), p, (B, L, T, d)
+        ctx.mem_slot = _MemoryGrad.enter(memory) if ctx.needs_input_grad[1] else None
+        ctx.tails = None
+        if os.environ.get("ATHENA_LAYER_TAIL_DECODER", "1") != "0" and \
+                ops.layer_tail_ok(t2, d, layer.attn1.dense) and \
+                ops.layer_tail_ok(t2, d, layer.attn2.dense, layer.ffn0, layer.ffn1):
+            # two launches besides the attention kernels and their q/k/v projections: self-attention
+            # projection + LayerNorm, then cross-attention projection + LayerNorm + FFN + LayerNorm
+            t2 = t2.contiguous()
+            c1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True, project=False)
+            ta = ops.layer_tail_fwd(c1, t2, layer.attn1.dense, layer.norm1, None, None, None, LN_EPS, p, rng,
+                                    layer.site_res1, 0, 0)
+            y1 = ta["y1"]
+            c2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False, project=False)
+            tb = ops.layer_tail_fwd(c2, y1, layer.attn2.dense, layer.norm2, layer.ffn0, layer.ffn1, layer.norm3,
+                                    LN_EPS, p, rng, layer.site_res2, layer.site_ffn_h, layer.site_res3)
+            y3 = tb.pop("y2")
+            ctx.tails = (ta, tb)
+            ctx.saved = (t2, m2, s1, s2)
+            return y3.view(B, L, d)
         a1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True)
         z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(t2, a1, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
                                                      layer.site_res1)
@@ -362,9 +382,7 @@ class DecoderLayerFn(torch.autograd.Function):
         f, s_ffn = ffn_fwd(y2, M, layer, p, rng)
         z3, y3, mean3, rstd3 = ops.add_layernorm_fwd(y2, f, layer.norm3.gamma, layer.norm3.beta, LN_EPS, p, rng,
                                                      layer.site_res3)
-        ctx.layer, ctx.masks, ctx.p, ctx.shape = layer, (tgt_key_mask, mem_key_mask), p, (B, L, T, d)
         ctx.saved = (t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3)
-        ctx.mem_slot = _MemoryGrad.enter(memory) if ctx.needs_input_grad[1] else None
         return y3.view(B, L, d)
 
     @staticmethod
@@ -374,9 +392,44 @@ class DecoderLayerFn(torch.autograd.Function):
         B, L, T, d = ctx.shape
         M = B * L
         rng = layer.store.rng_state
+        dy = dy.contiguous().view(M, d)
+        if ctx.tails is not None:
+            (ta, tb), ctx.tails = ctx.tails, None
+            t2, m2, s1, s2 = ctx.saved
+            ctx.saved = None
+            dff = layer.ffn0.out_features
+            rb = ops.layer_tail_bwd(dy, tb, layer.attn2.dense, layer.norm2, layer.ffn0, layer.ffn1, layer.norm3, p, rng,
+                                    layer.site_res2, layer.site_ffn_h, layer.site_res3)
+            if rb is None:
+                raise RuntimeError("decoder layer: the one-launch backward pass needs a running autograd pass")
+            df, dh, da2, d_y1, dctx2 = rb
+            y1 = ta["y1"]
+            lin_bwd_w(tb["h"], df, M, layer.ffn1, dff, d)
+            lin_bwd_w(tb["y1"], dh, M, layer.ffn0, d, dff)
+            lin_bwd_w(s2[3], da2, M, layer.attn2.dense, d, d)
+            slot = ctx.mem_slot
+            if slot is None:
+                dmem, acc_mem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device), False
+            else:
+                acc_mem = slot["buf"] is not None
+                if not acc_mem:
+                    slot["buf"] = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
+                dmem = slot["buf"]
+            mha_block_bwd(None, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, acc_mem,
+                          dctx=dctx2)
+            if slot is not None and not _MemoryGrad.leave(slot):
+                dmem = None
+            ra = ops.layer_tail_bwd(d_y1, ta, layer.attn1.dense, layer.norm1, None, None, None, p, rng,
+                                    layer.site_res1, 0, 0)
+            if ra is None:
+                raise RuntimeError("decoder layer: the one-launch backward pass needs a running autograd pass")
+            _, _, da1, dtgt, dctx1 = ra
+            lin_bwd_w(s1[3], da1, M, layer.attn1.dense, d, d)
+            mha_block_bwd(None, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True, dctx=dctx1)
+            return (dtgt.view(B, L, d), None if dmem is None else dmem.view(B, T, d), None, None, None, None) + \
+                (None,) * (len(ctx.needs_input_grad) - 6)
         t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3 = ctx.saved
         ctx.saved = None
-        dy = dy.contiguous().view(M, d)
         with weight_grad_group():
             d_y2, df = ops.add_layernorm_bwd(dy, z3, mean3, rstd3, layer.norm3.gamma, p, rng, layer.site_res3,
                                              layer.norm3.gamma.grad, layer.norm3.beta.grad)
