@@ -280,11 +280,30 @@ def pmc_traffic(workload, family):
         return None
 
 
+def profiled_family_ms(workload, label):
+    """Kernel time per step of a family in the committed ``rocprofv3 --kernel-trace --stats`` summary of
+    this benchmark (profiles/r2_bench_kernel_stats.txt, the table at its end), or None.  The event
+    pairs of the timing pass bracket dispatch gaps as well as kernels, and the calibrated pair cost
+    that is taken off again can overshoot; the family times of the bench line are therefore never
+    allowed to fall below the profiler's own sum of kernel durations."""
+    if workload != "aishell_b32_t1000":
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_bench_kernel_stats.txt")
+    try:
+        with open(path) as f:
+            for line in f:
+                if line.startswith(label):
+                    return float(line.split()[-2])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="aishell_b32_t1000")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -403,6 +422,10 @@ def main():
         solver.world_size, solver._force_exchange = was_dp
         fl = gemm_flops_parts(wl)
         g_ms, g_calls = kt.total_ms(list(GEMM_FAMILIES))
+        prof_ms = profiled_family_ms(args.workload, "GEMM cores")
+        clamped = prof_ms is not None and g_ms / nrep < prof_ms
+        scale = prof_ms * nrep / g_ms if clamped else 1.0          # applied to the family and its parts alike
+        g_ms *= scale
         flops = sum(fl.values())
         ach = flops * nrep / (g_ms * 1e-3) / 1e12
         roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel / gemm_big_kernel / gemm_big_table_kernel / "
@@ -411,17 +434,21 @@ def main():
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "gemm"),
                 "launches_per_step": g_calls // nrep, "ms_per_step": g_ms / nrep,
                 "avg_launch_us": 1e3 * g_ms / max(g_calls, 1), "event_pair_cost_us": 1e3 * kt.floor_ms,
-                "flops_per_step": flops}
+                "raised_to_profiled_kernel_time": bool(clamped), "flops_per_step": flops}
         parts = {}
         for key in GEMM_FAMILIES:
             ms, calls = kt.total_ms([key])
             if calls == 0:
                 continue
+            ms *= scale
             a_ = fl[key] * nrep / (ms * 1e-3) / 1e12
             parts[key] = {"bound": "mfma", "achieved": a_, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": a_ / MFMA_BF16_PEAK_TFLOPS, "ms_per_step": ms / nrep,
                           "launches_per_step": calls // nrep, "flops_per_step": fl[key]}
         a_ms, a_calls = kt.total_ms(["attention"])
+        prof_ms = profiled_family_ms(args.workload, "attention")
+        if a_calls and prof_ms is not None:
+            a_ms = max(a_ms, prof_ms * nrep)
         if a_calls:
             aa = attention_flops_per_step(wl) * nrep / (a_ms * 1e-3) / 1e12
             attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_*_mfma_kernel", "bound": "mfma",
@@ -429,6 +456,9 @@ def main():
                          "frac": aa / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "ms_per_step": a_ms / nrep,
                          "launches_per_step": a_calls // nrep}
         c_ms, _ = kt.total_ms(["ctc"])
+        prof_ms = profiled_family_ms(args.workload, "CTC")
+        if prof_ms is not None:
+            c_ms = max(c_ms, prof_ms * nrep)
         cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
         ctc_roof = {"kernel": "ctc_fwd_kernel (row logsumexp + lattice) + ctc_finish + ctc_grad", "bound": "hbm",
                     "achieved": cb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS,
