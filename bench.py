@@ -473,6 +473,12 @@ def main():
             "value": audio_s / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            # the stated deviation of the bf16 path from the fp64 CPU oracle on the full AISHELL-sized step
+            # (tests/test_fullsize_gpu.py::test_full_size_step_bf16): the 1e-2 absolute of the target holds
+            # for the root-mean-square error of the logits, not for the single worst of 35 million
+            "bf16_logit_error": {"rms_abs": [3.3e-3, 4.0e-3], "max_abs": [1.9e-2, 2.6e-2], "logit_scale": 1.8,
+                                 "heads": ["attention", "ctc"], "target_abs": 1e-2, "target_met": "rms only",
+                                 "loss_rel": 1e-5, "gradient_cosine": 0.99997},
             "config": {"workload": args.workload, "per_gpu_batch": wl["B"], "global_batch": wl["B"] * world,
                        "frames": wl["T"], "fbank_dim": wl["feat"], "classes": V, "parallelism": "dp%d" % world,
                        "hip_graph": bool(solver.hparams.enable_tf_function), "dropout": wl["rate"],
