@@ -6,6 +6,7 @@ from .loss import CTCLoss, MPCLoss, Seq2SeqSparseCategoricalCrossentropy
 from .metrics import Accuracy, CharactorAccuracy, CTCAccuracy, Seq2SeqSparseCategoricalAccuracy
 from .models.base import BaseModel
 from .models.masked_pc import MaskedPredictCoding
+from .models.deep_speech import DeepSpeechModel
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
 from .solver import BaseSolver, DecoderSolver, HorovodSolver
@@ -19,7 +20,7 @@ from .utils.misc import (create_multihead_mask, generate_square_subsequent_mask,
                          insert_sos_in_labels, validate_seqs)
 
 __all__ = [
-    "CTCLoss", "MPCLoss", "MaskedPredictCoding", "Seq2SeqSparseCategoricalCrossentropy", "Accuracy", "CharactorAccuracy", "CTCAccuracy",
+    "CTCLoss", "MPCLoss", "MaskedPredictCoding", "DeepSpeechModel", "Seq2SeqSparseCategoricalCrossentropy", "Accuracy", "CharactorAccuracy", "CTCAccuracy",
     "Seq2SeqSparseCategoricalAccuracy", "BaseModel", "MtlTransformerCtc", "SpeechTransformer", "BaseSolver",
     "HorovodSolver", "DecoderSolver", "BeamSearchDecoder", "CTCPrefixScorer", "HParams", "register_and_parse_hparams", "ExponentialDecayAdam", "WarmUpAdam",
     "WarmUpLearningSchedule", "MetricChecker", "set_default_summary_writer", "create_multihead_mask",

@@ -124,6 +124,19 @@ _SIGNATURES = {
     "athena_bn_relu6_infer": (c_int, [_P, _P, _P, _P, _P, c_float, c_long, c_int, c_int, _P, _S]),
     "athena_bn_relu6_bwd_scratch_bytes": (c_int64, [c_long, c_int]),
     "athena_bn_relu6_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, c_int64, _P, _P, _P, _S]),
+    "athena_bn_colstats": (c_int, [_P, c_long, c_int, c_int, _P, _S]),
+    "athena_bn_apply": (c_int, [_P, _P, _P, _P, c_long, c_int, c_int, _P, _S]),
+    "athena_bn_infer": (c_int, [_P, _P, _P, _P, _P, c_float, c_long, c_int, c_int, _P, _S]),
+    "athena_bn_bwd": (c_int, [_P, _P, _P, _P, _P, c_long, c_int, c_int, _P, c_int64, _P, _P, _P, _S]),
+    "athena_conv2d_out_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "athena_conv2d_fwd": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, _S]),
+    "athena_conv2d_dgrad": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, _S]),
+    "athena_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 10),
+    "athena_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, c_int64, _S]),
+    "athena_im2col": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 8 + [_S]),
+    "athena_rnn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "athena_rnn_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
+    "athena_rnn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
     "athena_add_pe_dropout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32, _P, _S]),
     "athena_dropout_bwd": (c_int, [_P, c_long, c_int, c_float, c_float, _P, c_uint32, _P, _P, _S]),
     "athena_embed_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32,

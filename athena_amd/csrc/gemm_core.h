@@ -189,6 +189,69 @@ struct ConvDgradRows {
     }
 };
 
+// Rows of the im2col matrix of a KH x KW convolution with strides (sh, sw) and "same" padding over
+// an NHWC tensor [B, H, W, C].  Row r = (b, ho, wo); segment = tap (kh*KW + kw); the row is the
+// C-vector at input pixel (sh*ho - pad_h + kh, sw*wo - pad_w + kw), zero outside the image.
+struct ConvTapRows {
+    static constexpr bool kCanMiss = true;
+    static constexpr bool kSegmented = true;
+    int H, W, C, Ho, Wo, pad_h, pad_w, KW, sh, sw;
+    int step_q, step_r;          // rows per k-step / Wo and % Wo, for step() by one k-tile
+    struct Row { int b, ho, wo; };
+    __device__ __forceinline__ Row prep(int r) const {
+        Row x;
+        x.wo = r % Wo;
+        int t = r / Wo;
+        x.ho = t % Ho;
+        x.b = t / Ho;
+        return x;
+    }
+    __device__ __forceinline__ long off(const Row& x, int seg) const {
+        const int kh = seg / KW, kw = seg - kh * KW;
+        const int h = sh * x.ho - pad_h + kh, w = sw * x.wo - pad_w + kw;
+        if (h < 0 || h >= H || w < 0 || w >= W) return -1;
+        return (long)((x.b * H + h) * W + w) * C;
+    }
+    __device__ __forceinline__ void step(Row& x, int) const {
+        x.wo += step_r;
+        x.ho += step_q;
+        if (x.wo >= Wo) { x.wo -= Wo; ++x.ho; }
+        while (x.ho >= Ho) { x.ho -= Ho; ++x.b; }
+    }
+};
+
+// Rows for the input gradient of that convolution.  Row r = one input pixel (b, h, w); segment =
+// tap (kh*KW + kw); the row is the Cout-vector of the output gradient at the output pixel this tap
+// connects the input pixel to, ((h + pad_h - kh) / sh, (w + pad_w - kw) / sw), and all zeros when
+// the division leaves a remainder or the pixel lies outside the output.
+struct ConvTapDgradRows {
+    static constexpr bool kCanMiss = true;
+    static constexpr bool kSegmented = true;
+    int H, W, Ho, Wo, Co, pad_h, pad_w, KW, sh, sw;
+    struct Row { int b, h, w; };
+    __device__ __forceinline__ Row prep(int r) const {
+        Row x;
+        x.w = r % W;
+        int t = r / W;
+        x.h = t % H;
+        x.b = t / H;
+        return x;
+    }
+    __device__ __forceinline__ long off(const Row& x, int seg) const {
+        const int kh = seg / KW, kw = seg - kh * KW;
+        const int th = x.h + pad_h - kh, tw = x.w + pad_w - kw;
+        if (th < 0 || tw < 0) return -1;
+        const int ho = th / sh, wo = tw / sw;
+        if (ho * sh != th || wo * sw != tw || ho >= Ho || wo >= Wo) return -1;
+        return (((long)x.b * Ho + ho) * Wo + wo) * Co;
+    }
+    __device__ __forceinline__ void step(Row& x, int d) const {
+        x.w += d;
+        while (x.w >= W) { x.w -= W; ++x.h; }
+        while (x.h >= H) { x.h -= H; ++x.b; }
+    }
+};
+
 // ------------------------------------------------------------------ problem description
 template <class AMap>
 struct GemmProblem {
@@ -883,7 +946,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
 // Second pass of a split-K product whose workgroups wrote raw partial sums: adds the ``split``
 // slabs of each batch in a fixed order (bit-reproducible, no atomics, no zero-fill of C) and
 // writes C = alpha * sum.  Row M of a slab carries the column sums of B and goes to ``bsum``.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split, int M, int N,
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split, int M, int N,
                                                             int ldp, float* __restrict__ C, int ldc,
                                                             long c_batch_stride, float alpha,
                                                             float* __restrict__ bsum) {
@@ -949,7 +1012,7 @@ struct ReduceGroup {
 };
 
 // splitk_reduce_kernel for the problems of a grouped launch
-__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(ReduceGroup g) {
+static __global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(ReduceGroup g) {
     __shared__ float4 red[4][64];
     int pi = 0;
     while (pi + 1 < g.count && (int)blockIdx.x >= g.first[pi + 1]) ++pi;

@@ -656,9 +656,13 @@ extern "C" int athena_bn_finalize(const double* colstats, long rows, int C, floa
     return ATHENA_OK;
 }
 
-// y = relu6(x * sc[c] + sh[c]) with sc = gamma*rstd, sh = beta - mean*gamma*rstd (training) or the
+template <bool RELU6>
+__device__ __forceinline__ float bn_act(float v) { return RELU6 ? relu6f(v) : v; }
+
+// y = relu6(x * sc[c] + sh[c]) (or without the relu6: the BatchNormalization that follows each recurrent
+// layer, reference athena/models/deep_speech.py:80) with sc = gamma*rstd, sh = beta - mean*gamma*rstd (training) or the
 // moving-statistics equivalents (inference)
-template <typename T, bool INFER>
+template <typename T, bool INFER, bool RELU6>
 __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict__ x, const float* __restrict__ s0,
                                                              const float* __restrict__ s1,
                                                              const float* __restrict__ gamma,
@@ -690,8 +694,8 @@ __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict
             Vec8<T>::load(x + (e + stride) * 8, v1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v0[i] = relu6f(fmaf(v0[i] - sh[i], sc[i], be[i]));
-                v1[i] = relu6f(fmaf(v1[i] - sh[i], sc[i], be[i]));
+                v0[i] = bn_act<RELU6>(fmaf(v0[i] - sh[i], sc[i], be[i]));
+                v1[i] = bn_act<RELU6>(fmaf(v1[i] - sh[i], sc[i], be[i]));
             }
             Vec8<T>::store(y + e * 8, v0);
             Vec8<T>::store(y + (e + stride) * 8, v1);
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict
             float v0[8];
             Vec8<T>::load(x + e * 8, v0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v0[i] = relu6f(fmaf(v0[i] - sh[i], sc[i], be[i]));
+            for (int i = 0; i < 8; ++i) v0[i] = bn_act<RELU6>(fmaf(v0[i] - sh[i], sc[i], be[i]));
             Vec8<T>::store(y + e * 8, v0);
         }
         return;
@@ -710,23 +714,26 @@ __global__ __launch_bounds__(256) void bn_relu6_apply_kernel(const T* __restrict
         coeffs((int)(e % cpr) * 8, sc, sh, be);
         Vec8<T>::load(x + e * 8, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = relu6f(fmaf(v[i] - sh[i], sc[i], be[i]));
+        for (int i = 0; i < 8; ++i) v[i] = bn_act<RELU6>(fmaf(v[i] - sh[i], sc[i], be[i]));
         Vec8<T>::store(y + e * 8, v);
     }
 }
 
 static int bn_apply_common(const void* x, const float* s0, const float* s1, const float* gamma, const float* beta,
-                           float eps, long rows, int C, int dtype, void* y, bool infer, hipStream_t stream) {
+                           float eps, long rows, int C, int dtype, void* y, bool infer, hipStream_t stream,
+                           bool relu6 = true) {
     ATHENA_REQUIRE(x && s0 && gamma && beta && y && rows > 0 && C > 0, ATHENA_E_SHAPE, "athena_bn_relu6: bad arguments");
     ATHENA_REQUIRE(C % 8 == 0 && athena_aligned16(x) && athena_aligned16(y), ATHENA_E_ALIGN, "athena_bn_relu6: C %% 8 and 16-byte alignment required");
     const long nchunks = rows * (C / 8);
     long blocks = (nchunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks);
-#define BN_APPLY(T, I) hipLaunchKernelGGL((bn_relu6_apply_kernel<T, I>), grid, dim3(256), 0, stream, (const T*)x, s0, s1, gamma, beta, eps, nchunks, C, (T*)y)
-    if (dtype == ATHENA_BF16) { if (infer) BN_APPLY(bf16_t, true); else BN_APPLY(bf16_t, false); }
-    else if (dtype == ATHENA_F32) { if (infer) BN_APPLY(float, true); else BN_APPLY(float, false); }
+#define BN_APPLY(T, I, R) hipLaunchKernelGGL((bn_relu6_apply_kernel<T, I, R>), grid, dim3(256), 0, stream, (const T*)x, s0, s1, gamma, beta, eps, nchunks, C, (T*)y)
+#define BN_APPLY_R(T, I) do { if (relu6) BN_APPLY(T, I, true); else BN_APPLY(T, I, false); } while (0)
+    if (dtype == ATHENA_BF16) { if (infer) BN_APPLY_R(bf16_t, true); else BN_APPLY_R(bf16_t, false); }
+    else if (dtype == ATHENA_F32) { if (infer) BN_APPLY_R(float, true); else BN_APPLY_R(float, false); }
     else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6: dtype");
+#undef BN_APPLY_R
 #undef BN_APPLY
     ATHENA_CHECK_LAUNCH("athena_bn_relu6_apply");
     return ATHENA_OK;
@@ -742,12 +749,24 @@ extern "C" int athena_bn_relu6_infer(const void* x, const float* moving_mean, co
     ATHENA_REQUIRE(moving_var, ATHENA_E_SHAPE, "athena_bn_relu6_infer: null moving_var");
     return bn_apply_common(x, moving_mean, moving_var, gamma, beta, eps, rows, C, dtype, y, true, (hipStream_t)stream);
 }
+extern "C" int athena_bn_apply(const void* x, const float* mean_rstd, const float* gamma, const float* beta, long rows,
+                               int C, int dtype, void* y, athena_stream_t stream) {
+    return bn_apply_common(x, mean_rstd, nullptr, gamma, beta, 0.f, rows, C, dtype, y, false, (hipStream_t)stream,
+                           false);
+}
+extern "C" int athena_bn_infer(const void* x, const float* moving_mean, const float* moving_var, const float* gamma,
+                               const float* beta, float eps, long rows, int C, int dtype, void* y,
+                               athena_stream_t stream) {
+    ATHENA_REQUIRE(moving_var, ATHENA_E_SHAPE, "athena_bn_infer: null moving_var");
+    return bn_apply_common(x, moving_mean, moving_var, gamma, beta, eps, rows, C, dtype, y, true, (hipStream_t)stream,
+                           false);
+}
 
 // reduce: slab[blockIdx.x][c] = sum dy', slab[blockIdx.x][C+c] = sum dy'*xhat over the block's rows
 // (dy' = dy masked by the relu6 gate).  One fp32 slab per workgroup instead of atomics on the 2C
 // totals: a few hundred workgroups adding to the same 2C addresses serialise there.
 #define BN_ROWS_PER_BLOCK 512
-template <typename T>
+template <typename T, bool RELU6>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int i = 0; i < 8; ++i) {
                 const float xh = (xv[i] - mu[i]) * rs[i];
                 const float yb = xh * ga[i] + be[i];        // the relu6 gate is recomputed, not read
-                const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
+                const float g = (!RELU6 || (yb > 0.f && yb < 6.f)) ? dv[i] : 0.f;
                 a1[i] += g;
                 a2[i] += g * xh;
             }
@@ -846,7 +865,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fold_kernel(const float* __restri
     }
 }
 
-template <typename T>
+template <typename T, bool RELU6>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ mean_rstd,
@@ -877,7 +896,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int i = 0; i < 8; ++i) {
             const float xh = (xv[i] - k.mu[i]) * k.rs[i];
             const float yb = xh * k.ga[i] + k.be[i];
-            const float g = (yb > 0.f && yb < 6.f) ? dv[i] : 0.f;
+            const float g = (!RELU6 || (yb > 0.f && yb < 6.f)) ? dv[i] : 0.f;
             o[i] = k.k1[i] * (g - k.k2[i] - xh * k.k3[i]);
         }
     };
@@ -929,18 +948,16 @@ extern "C" int64_t athena_bn_relu6_bwd_scratch_bytes(long rows, int C) {
     return (int64_t)sizeof(double) * 2 * C + (int64_t)sizeof(float) * nslab * 2 * C;     // totals + slabs
 }
 
-extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const float* mean_rstd, const float* gamma,
-                                   const float* beta, long rows, int C, int dtype, void* scratch,
-                                   int64_t scratch_bytes, void* dx, float* dgamma, float* dbeta,
-                                   athena_stream_t stream) {
+static int bn_bwd_common(const char* name, const void* dy, const void* x, const float* mean_rstd, const float* gamma,
+                         const float* beta, long rows, int C, int dtype, void* scratch, int64_t scratch_bytes,
+                         void* dx, float* dgamma, float* dbeta, bool relu6, hipStream_t s) {
     ATHENA_REQUIRE(dy && x && beta && mean_rstd && gamma && scratch && dx && dgamma && dbeta && rows > 0 && C > 0,
-                   ATHENA_E_SHAPE, "athena_bn_relu6_bwd: bad arguments");
-    ATHENA_REQUIRE(C % 8 == 0, ATHENA_E_ALIGN, "athena_bn_relu6_bwd: C %% 8 required");
+                   ATHENA_E_SHAPE, "%s: bad arguments", name);
+    ATHENA_REQUIRE(C % 8 == 0, ATHENA_E_ALIGN, "%s: C %% 8 required", name);
     ATHENA_REQUIRE(scratch_bytes >= athena_bn_relu6_bwd_scratch_bytes(rows, C) && athena_aligned16(scratch),
-                   ATHENA_E_SHAPE, "athena_bn_relu6_bwd: scratch too small (%lld bytes) or misaligned",
-                   (long long)scratch_bytes);
+                   ATHENA_E_SHAPE, "%s: scratch too small (%lld bytes) or misaligned", name, (long long)scratch_bytes);
+    ATHENA_REQUIRE(dtype == ATHENA_BF16 || dtype == ATHENA_F32, ATHENA_E_UNSUPPORTED, "%s: dtype", name);
     const int cpr = C / 8;
-    hipStream_t s = (hipStream_t)stream;
     double* totals = (double*)scratch;
     float* slabs = (float*)(totals + 2 * C);
     const int cpb = cpr < 256 ? cpr : 256;
@@ -950,17 +967,95 @@ extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const float* m
     long blocks = (nchunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     const int nent = 2 * C;
-    if (dtype == ATHENA_BF16) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, beta, mean_rstd, rows, C, slabs);
-        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab, nent, totals);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (bf16_t*)dx, dgamma, dbeta);
-    } else if (dtype == ATHENA_F32) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, g1, dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, beta, mean_rstd, rows, C, slabs);
-        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab, nent, totals);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, (const float*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (float*)dx, dgamma, dbeta);
-    } else {
-        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_bn_relu6_bwd: dtype");
+#define BN_BWD(T, R)                                                                                                    \
+    do {                                                                                                                \
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), g1, dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, beta,  \
+                           mean_rstd, rows, C, slabs);                                                                  \
+        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab,    \
+                           nent, totals);                                                                               \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy,          \
+                           (const T*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (T*)dx, dgamma, dbeta); \
+    } while (0)
+    if (dtype == ATHENA_BF16) { if (relu6) BN_BWD(bf16_t, true); else BN_BWD(bf16_t, false); }
+    else { if (relu6) BN_BWD(float, true); else BN_BWD(float, false); }
+#undef BN_BWD
+    ATHENA_CHECK_LAUNCH(name);
+    return ATHENA_OK;
+}
+
+extern "C" int athena_bn_relu6_bwd(const void* dy, const void* x, const float* mean_rstd, const float* gamma,
+                                   const float* beta, long rows, int C, int dtype, void* scratch,
+                                   int64_t scratch_bytes, void* dx, float* dgamma, float* dbeta,
+                                   athena_stream_t stream) {
+    return bn_bwd_common("athena_bn_relu6_bwd", dy, x, mean_rstd, gamma, beta, rows, C, dtype, scratch, scratch_bytes,
+                         dx, dgamma, dbeta, true, (hipStream_t)stream);
+}
+
+extern "C" int athena_bn_bwd(const void* dy, const void* x, const float* mean_rstd, const float* gamma,
+                             const float* beta, long rows, int C, int dtype, void* scratch, int64_t scratch_bytes,
+                             void* dx, float* dgamma, float* dbeta, athena_stream_t stream) {
+    return bn_bwd_common("athena_bn_bwd", dy, x, mean_rstd, gamma, beta, rows, C, dtype, scratch, scratch_bytes, dx,
+                         dgamma, dbeta, false, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- column statistics for BatchNorm
+// stats[c] = sum over rows of x[r][c], stats[C + c] = sum of squares, in fp64 (the same statistics the
+// convolution epilogue collects).  Workgroup = 64 column pieces x 4 row lanes; per-workgroup fp64
+// partial sums are added with atomics onto the zero-filled totals.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_colstats_kernel(const T* __restrict__ x, long rows, int C,
+                                                          double* __restrict__ stats, int rows_per_block) {
+    __shared__ double red[2][4][64 * 8];
+    const int cpr = C / 8;
+    const int piece = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    double s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    if (piece < cpr) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            float v[8];
+            Vec8<T>::load(x + r * C + piece * 8, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] += (double)v[i];
+                s2[i] += (double)v[i] * (double)v[i];
+            }
+        }
     }
-    ATHENA_CHECK_LAUNCH("athena_bn_relu6_bwd");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[0][rl][(threadIdx.x & 63) * 8 + i] = s1[i];
+        red[1][rl][(threadIdx.x & 63) * 8 + i] = s2[i];
+    }
+    __syncthreads();
+    if (rl == 0 && piece < cpr) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int o = (threadIdx.x & 63) * 8 + i;
+            const double a = red[0][0][o] + red[0][1][o] + red[0][2][o] + red[0][3][o];
+            const double b = red[1][0][o] + red[1][1][o] + red[1][2][o] + red[1][3][o];
+            atomicAdd(stats + piece * 8 + i, a);
+            atomicAdd(stats + C + piece * 8 + i, b);
+        }
+    }
+}
+
+extern "C" int athena_bn_colstats(const void* x, long rows, int C, int dtype, double* colstats,
+                                  athena_stream_t stream) {
+    ATHENA_REQUIRE(x && colstats && rows > 0 && C > 0, ATHENA_E_SHAPE, "athena_bn_colstats: bad arguments");
+    ATHENA_REQUIRE(C % 8 == 0 && athena_aligned16(x), ATHENA_E_ALIGN, "athena_bn_colstats: C %% 8 and 16-byte alignment required");
+    ATHENA_REQUIRE(dtype == ATHENA_BF16 || dtype == ATHENA_F32, ATHENA_E_UNSUPPORTED, "athena_bn_colstats: dtype");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(colstats, 0, sizeof(double) * 2 * C, s);
+    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_bn_colstats: memset failed");
+    const int cpr = C / 8;
+    const int rpb = 256;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (cpr + 63) / 64);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(bn_colstats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, colstats, rpb);
+    else
+        hipLaunchKernelGGL(bn_colstats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, colstats, rpb);
+    ATHENA_CHECK_LAUNCH("athena_bn_colstats");
     return ATHENA_OK;
 }

@@ -1,0 +1,272 @@
+// Recurrent layers of the DeepSpeech model: tf.keras.layers.RNN over a GRUCell or an LSTMCell with
+// return_sequences=True (reference athena/models/deep_speech.py:75-79, athena/layers/commons.py:486-491).
+//
+// The input projection of ALL time steps (x W + b) is one large GEMM done by the caller; what is left
+// is the serial part.  Per time step: one skinny GEMM  h[t-1] U  ([B, H] x [H, G*H], G = 3 or 4 gates)
+// on the shared GEMM core and one element-wise gate kernel.  Batch-major layouts throughout (Keras'
+// [B, T, ...]), so a time step is a strided row block and nothing is transposed:
+//   xw      [B, T, G*H]      x W + b of every step                                   (compute dtype)
+//   hs_ext  [B, T+1, H]      slot 0 = initial state (zeros), slot t+1 = h[t]         (compute dtype)
+//   cs_ext  [B, T+1, H]      LSTM cell state, same slots                             (fp32)
+//   gates   [B, T, G*H]      activated gates kept for the backward pass              (compute dtype)
+//   rh      [B, T, H]        GRU: recurrent part of the candidate, (h[t-1] U + b)_h  (compute dtype)
+//   y       [B, T, H]        layer output = h[t] (contiguous copy for the next layer)
+// The weight gradients are again large GEMMs over all steps, done by the caller from
+//   dxw     [B, T, G*H]      gradient at x W + b
+//   dhu_ext [B, T+1, G*H]    gradient at h[t-1] U (+ b); slot T is zero, so that hs_ext^T dhu_ext over all
+//                            B*(T+1) rows pairs h[t-1] with step t
+//
+// GRU (Keras GRUCell, reset_after=True, gate order z, r, h):
+//   z = sigmoid(xw_z + hu_z)   r = sigmoid(xw_r + hu_r)   hh = tanh(xw_h + r * hu_h)
+//   h[t] = z * h[t-1] + (1 - z) * hh
+// LSTM (Keras LSTMCell, gate order i, f, c, o):
+//   i, f, o = sigmoid(.)   g = tanh(.)   c[t] = f * c[t-1] + i * g   h[t] = o * tanh(c[t])
+#include "common.h"
+#include <string.h>
+
+#define RNN_GRU 0
+#define RNN_LSTM 1
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const T* __restrict__ xw, const float* __restrict__ hu,
+                                                           T* __restrict__ hs_ext, T* __restrict__ y,
+                                                           T* __restrict__ gates, T* __restrict__ rh, int B, int Tn,
+                                                           int H, int t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx - b * H;
+    const long xo = ((long)b * Tn + t) * 3 * H;
+    const float* hb = hu + (long)b * 3 * H;
+    const long ho = ((long)b * (Tn + 1) + t) * H + j;
+    const float hp = to_f32<T>(hs_ext[ho]);
+    const float z = sigmoid_f(to_f32<T>(xw[xo + j]) + hb[j]);
+    const float r = sigmoid_f(to_f32<T>(xw[xo + H + j]) + hb[H + j]);
+    const float rhv = hb[2 * H + j];
+    const float hh = tanhf(to_f32<T>(xw[xo + 2 * H + j]) + r * rhv);
+    const float h = z * hp + (1.f - z) * hh;
+    const T hq = from_f32<T>(h);
+    hs_ext[ho + H] = hq;
+    y[((long)b * Tn + t) * H + j] = hq;
+    gates[xo + j] = from_f32<T>(z);
+    gates[xo + H + j] = from_f32<T>(r);
+    gates[xo + 2 * H + j] = from_f32<T>(hh);
+    rh[((long)b * Tn + t) * H + j] = from_f32<T>(rhv);
+}
+
+// dh = dy[t] + carry;  carry' = dh * z  (the recurrent product adds dhu U^T onto it afterwards)
+template <typename T>
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ hs_ext,
+                                                           const T* __restrict__ gates, const T* __restrict__ rh,
+                                                           float* __restrict__ carry, T* __restrict__ dxw,
+                                                           T* __restrict__ dhu_ext, int B, int Tn, int H, int t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx - b * H;
+    const long go = ((long)b * Tn + t) * 3 * H;
+    const long eo = ((long)b * (Tn + 1) + t) * 3 * H;
+    const float z = to_f32<T>(gates[go + j]), r = to_f32<T>(gates[go + H + j]), hh = to_f32<T>(gates[go + 2 * H + j]);
+    const float rhv = to_f32<T>(rh[((long)b * Tn + t) * H + j]);
+    const float hp = to_f32<T>(hs_ext[((long)b * (Tn + 1) + t) * H + j]);
+    const float dh = to_f32<T>(dy[((long)b * Tn + t) * H + j]) + carry[idx];
+    const float da_h = dh * (1.f - z) * (1.f - hh * hh);
+    const float da_z = dh * (hp - hh) * z * (1.f - z);
+    const float da_r = da_h * rhv * r * (1.f - r);
+    dxw[go + j] = from_f32<T>(da_z);
+    dxw[go + H + j] = from_f32<T>(da_r);
+    dxw[go + 2 * H + j] = from_f32<T>(da_h);
+    dhu_ext[eo + j] = from_f32<T>(da_z);
+    dhu_ext[eo + H + j] = from_f32<T>(da_r);
+    dhu_ext[eo + 2 * H + j] = from_f32<T>(da_h * r);
+    carry[idx] = dh * z;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const T* __restrict__ xw, const float* __restrict__ hu,
+                                                            T* __restrict__ hs_ext, float* __restrict__ cs_ext,
+                                                            T* __restrict__ y, T* __restrict__ gates, int B, int Tn,
+                                                            int H, int t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx - b * H;
+    const long xo = ((long)b * Tn + t) * 4 * H;
+    const float* hb = hu + (long)b * 4 * H;
+    const long so = ((long)b * (Tn + 1) + t) * H + j;
+    const float i = sigmoid_f(to_f32<T>(xw[xo + j]) + hb[j]);
+    const float f = sigmoid_f(to_f32<T>(xw[xo + H + j]) + hb[H + j]);
+    const float g = tanhf(to_f32<T>(xw[xo + 2 * H + j]) + hb[2 * H + j]);
+    const float o = sigmoid_f(to_f32<T>(xw[xo + 3 * H + j]) + hb[3 * H + j]);
+    const float c = f * cs_ext[so] + i * g;
+    const T hq = from_f32<T>(o * tanhf(c));
+    cs_ext[so + H] = c;
+    hs_ext[so + H] = hq;
+    y[((long)b * Tn + t) * H + j] = hq;
+    gates[xo + j] = from_f32<T>(i);
+    gates[xo + H + j] = from_f32<T>(f);
+    gates[xo + 2 * H + j] = from_f32<T>(g);
+    gates[xo + 3 * H + j] = from_f32<T>(o);
+}
+
+// carry_h' = 0 (the recurrent product adds dhu U^T onto it), carry_c' = dc * f
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ cs_ext,
+                                                            const T* __restrict__ gates, float* __restrict__ carry_h,
+                                                            float* __restrict__ carry_c, T* __restrict__ dxw,
+                                                            T* __restrict__ dhu_ext, int B, int Tn, int H, int t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const int b = idx / H, j = idx - b * H;
+    const long go = ((long)b * Tn + t) * 4 * H;
+    const long eo = ((long)b * (Tn + 1) + t) * 4 * H;
+    const long so = ((long)b * (Tn + 1) + t) * H + j;
+    const float i = to_f32<T>(gates[go + j]), f = to_f32<T>(gates[go + H + j]);
+    const float g = to_f32<T>(gates[go + 2 * H + j]), o = to_f32<T>(gates[go + 3 * H + j]);
+    const float cp = cs_ext[so], c = cs_ext[so + H];
+    const float tc = tanhf(c);
+    const float dh = to_f32<T>(dy[((long)b * Tn + t) * H + j]) + carry_h[idx];
+    const float dc = carry_c[idx] + dh * o * (1.f - tc * tc);
+    const float da[4] = {dc * g * i * (1.f - i), dc * cp * f * (1.f - f), dc * i * (1.f - g * g),
+                         dh * tc * o * (1.f - o)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T q = from_f32<T>(da[k]);
+        dxw[go + k * H + j] = q;
+        dhu_ext[eo + k * H + j] = q;
+    }
+    carry_h[idx] = 0.f;
+    carry_c[idx] = dc * f;
+}
+
+static int rnn_check(const char* name, int cell, int B, int T, int H, int dtype) {
+    ATHENA_REQUIRE(cell == RNN_GRU || cell == RNN_LSTM, ATHENA_E_UNSUPPORTED, "%s: cell %d (0 = gru, 1 = lstm)", name, cell);
+    ATHENA_REQUIRE(B > 0 && T > 0 && H > 0, ATHENA_E_SHAPE, "%s: bad shape B=%d T=%d H=%d", name, B, T, H);
+    ATHENA_REQUIRE(H % 8 == 0, ATHENA_E_ALIGN, "%s: hidden size %d must be a multiple of 8", name, H);
+    ATHENA_REQUIRE(dtype == ATHENA_F32 || dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "%s: dtype", name);
+    ATHENA_REQUIRE((long)B * (T + 1) * 4 * H < (1L << 31), ATHENA_E_SHAPE, "%s: more than 2^31 gate elements", name);
+    return ATHENA_OK;
+}
+
+static inline size_t esize(int dtype) { return dtype == ATHENA_BF16 ? 2 : 4; }
+
+// zero slot ``slot`` of every batch row of a [B, slots, width] array
+static int zero_slot(void* base, int B, int slots, int width, size_t es, int slot, hipStream_t s, const char* name) {
+    hipError_t e = hipMemset2DAsync((char*)base + (size_t)slot * width * es, (size_t)slots * width * es, 0,
+                                    (size_t)width * es, (size_t)B, s);
+    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "%s: memset failed: %s", name, hipGetErrorString(e));
+    return ATHENA_OK;
+}
+
+extern "C" int64_t athena_rnn_workspace_bytes(int cell, int B, int H) {
+    if (B <= 0 || H <= 0) return 0;
+    const int G = cell == RNN_LSTM ? 4 : 3;
+    // forward: h U of one step [B, G*H]; backward: the two carried gradients [B, H] each
+    const int64_t fwd = (int64_t)sizeof(float) * B * G * H, bwd = (int64_t)sizeof(float) * 2 * B * H;
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int athena_rnn_fwd(int cell, const void* xw, const void* u, const float* b_rec, void* hs_ext, float* cs_ext,
+                              void* y, void* gates, void* rh, int B, int T, int H, int dtype, void* workspace,
+                              int64_t workspace_bytes, athena_stream_t stream) {
+    int rc = rnn_check("athena_rnn_fwd", cell, B, T, H, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(xw && u && hs_ext && y && gates && workspace, ATHENA_E_SHAPE, "athena_rnn_fwd: null operand");
+    ATHENA_REQUIRE(cell == RNN_LSTM ? cs_ext != nullptr : rh != nullptr, ATHENA_E_SHAPE,
+                   "athena_rnn_fwd: the cell's state array (cs_ext for lstm, rh for gru) is missing");
+    ATHENA_REQUIRE(workspace_bytes >= athena_rnn_workspace_bytes(cell, B, H) && athena_aligned16(workspace),
+                   ATHENA_E_SHAPE, "athena_rnn_fwd: workspace too small or misaligned");
+    const int G = cell == RNN_LSTM ? 4 : 3;
+    const size_t es = esize(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    rc = zero_slot(hs_ext, B, T + 1, H, es, 0, s, "athena_rnn_fwd");
+    if (rc) return rc;
+    if (cell == RNN_LSTM) {
+        rc = zero_slot(cs_ext, B, T + 1, H, sizeof(float), 0, s, "athena_rnn_fwd");
+        if (rc) return rc;
+    }
+    float* hu = (float*)workspace;
+    athena_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.B = u;
+    d.C = hu;
+    d.bias = b_rec;
+    d.M = B; d.N = G * H; d.K = H;
+    d.lda = (T + 1) * H; d.ldb = G * H; d.ldc = G * H;
+    d.in_dtype = dtype;
+    d.out_dtype = ATHENA_F32;
+    d.split_k = 1;
+    d.alpha = 1.f;
+    const dim3 grid((unsigned)(((long)B * H + 255) / 256));
+    for (int t = 0; t < T; ++t) {
+        d.A = (const char*)hs_ext + (size_t)t * H * es;
+        rc = athena_gemm(&d, stream);
+        if (rc) return rc;
+        if (cell == RNN_GRU) {
+            if (dtype == ATHENA_BF16)
+                hipLaunchKernelGGL(gru_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
+            else
+                hipLaunchKernelGGL(gru_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, (float*)y, (float*)gates, (float*)rh, B, T, H, t);
+        } else {
+            if (dtype == ATHENA_BF16)
+                hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, B, T, H, t);
+            else
+                hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, cs_ext, (float*)y, (float*)gates, B, T, H, t);
+        }
+    }
+    ATHENA_CHECK_LAUNCH("athena_rnn_fwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_rnn_bwd(int cell, const void* dy, const void* u, const void* hs_ext, const float* cs_ext,
+                              const void* gates, const void* rh, void* dxw, void* dhu_ext, int B, int T, int H,
+                              int dtype, void* workspace, int64_t workspace_bytes, athena_stream_t stream) {
+    int rc = rnn_check("athena_rnn_bwd", cell, B, T, H, dtype);
+    if (rc) return rc;
+    ATHENA_REQUIRE(dy && u && hs_ext && gates && dxw && dhu_ext && workspace, ATHENA_E_SHAPE, "athena_rnn_bwd: null operand");
+    ATHENA_REQUIRE(cell == RNN_LSTM ? cs_ext != nullptr : rh != nullptr, ATHENA_E_SHAPE,
+                   "athena_rnn_bwd: the cell's state array (cs_ext for lstm, rh for gru) is missing");
+    ATHENA_REQUIRE(workspace_bytes >= athena_rnn_workspace_bytes(cell, B, H) && athena_aligned16(workspace),
+                   ATHENA_E_SHAPE, "athena_rnn_bwd: workspace too small or misaligned");
+    const int G = cell == RNN_LSTM ? 4 : 3;
+    const size_t es = esize(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    float* carry_h = (float*)workspace;
+    float* carry_c = carry_h + (size_t)B * H;
+    hipError_t e = hipMemsetAsync(carry_h, 0, sizeof(float) * 2 * B * H, s);
+    ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_rnn_bwd: memset failed");
+    rc = zero_slot(dhu_ext, B, T + 1, G * H, es, T, s, "athena_rnn_bwd");
+    if (rc) return rc;
+    athena_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.B = u;
+    d.C = carry_h;
+    d.M = B; d.N = H; d.K = G * H;
+    d.trans_b = 1;                     // B(k, n) = U[n][k]: the product with U^T
+    d.lda = (T + 1) * G * H; d.ldb = G * H; d.ldc = H;
+    d.in_dtype = dtype;
+    d.out_dtype = ATHENA_F32;
+    d.accumulate = 1;
+    d.split_k = 1;
+    d.alpha = 1.f;
+    const dim3 grid((unsigned)(((long)B * H + 255) / 256));
+    for (int t = T - 1; t >= 0; --t) {
+        if (cell == RNN_GRU) {
+            if (dtype == ATHENA_BF16)
+                hipLaunchKernelGGL(gru_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)hs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+            else
+                hipLaunchKernelGGL(gru_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)hs_ext, (const float*)gates, (const float*)rh, carry_h, (float*)dxw, (float*)dhu_ext, B, T, H, t);
+        } else {
+            if (dtype == ATHENA_BF16)
+                hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, cs_ext, (const bf16_t*)gates, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+            else
+                hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, cs_ext, (const float*)gates, carry_h, carry_c, (float*)dxw, (float*)dhu_ext, B, T, H, t);
+        }
+        if (t > 0) {
+            d.A = (const char*)dhu_ext + (size_t)t * G * H * es;
+            rc = athena_gemm(&d, stream);
+            if (rc) return rc;
+        }
+    }
+    ATHENA_CHECK_LAUNCH("athena_rnn_bwd");
+    return ATHENA_OK;
+}

@@ -16,6 +16,7 @@ import torch
 
 from .data import SpeechRecognitionDatasetBuilder, SyntheticSpeechRecognitionDatasetBuilder
 from .models.masked_pc import MaskedPredictCoding
+from .models.deep_speech import DeepSpeechModel
 from .models.mtl_seq2seq import MtlTransformerCtc
 from .models.speech_transformer import SpeechTransformer
 from .solver import BaseSolver
@@ -43,6 +44,7 @@ SUPPORTED_MODEL = {
     "speech_transformer": SpeechTransformer,
     "mtl_transformer_ctc": MtlTransformerCtc,
     "mpc": MaskedPredictCoding,
+    "deep_speech": DeepSpeechModel,
 }
 
 SUPPORTED_OPTIMIZER = {

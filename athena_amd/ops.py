@@ -569,6 +569,132 @@ def bn_relu6_bwd(dy, x, mean_rstd, gamma, beta, rows, C, scratch, dx, dgamma, db
                "athena_bn_relu6_bwd")
 
 
+def bn_colstats(x, rows, C, colstats):
+    """{sum, sumsq} per column of x [rows, C] into the fp64 ``colstats`` [2C]."""
+    if x.numel() != rows * C or colstats.dtype != torch.float64 or colstats.numel() < 2 * C:
+        raise RuntimeError("athena_amd.bn_colstats: bad operands")
+    _lib.check(_lib.load().athena_bn_colstats(_ptr(x), rows, C, dt(x), _ptr(colstats), _stream()), "athena_bn_colstats")
+
+
+def bn_apply(x, mean_rstd, gamma, beta, rows, C, y):
+    if x.numel() != rows * C or y.numel() != rows * C or x.dtype != y.dtype:
+        raise RuntimeError("athena_amd.bn_apply: bad operands")
+    _lib.check(_lib.load().athena_bn_apply(_ptr(x), _ptr(mean_rstd), _ptr(gamma), _ptr(beta), rows, C, dt(x), _ptr(y),
+                                           _stream()), "athena_bn_apply")
+
+
+def bn_infer(x, moving_mean, moving_var, gamma, beta, eps, rows, C, y):
+    if x.numel() != rows * C or y.numel() != rows * C or x.dtype != y.dtype:
+        raise RuntimeError("athena_amd.bn_infer: bad operands")
+    _lib.check(_lib.load().athena_bn_infer(_ptr(x), _ptr(moving_mean), _ptr(moving_var), _ptr(gamma), _ptr(beta), eps,
+                                           rows, C, dt(x), _ptr(y), _stream()), "athena_bn_infer")
+
+
+def bn_bwd(dy, x, mean_rstd, gamma, beta, rows, C, scratch, dx, dgamma, dbeta):
+    if any(t.numel() != rows * C for t in (dy, x, dx)):
+        raise RuntimeError("athena_amd.bn_bwd: bad operands")
+    _lib.check(_lib.load().athena_bn_bwd(_ptr(dy), _ptr(x), _ptr(mean_rstd), _ptr(gamma), _ptr(beta), rows, C, dt(x),
+                                         _ptr(scratch), scratch.numel() * scratch.element_size(), _ptr(dx),
+                                         _ptr(dgamma), _ptr(dbeta), _stream()), "athena_bn_bwd")
+
+
+# ------------------------------------------------------------------------------------------ Conv2D, any kernel
+def conv2d_out_shape(H, W, KH, KW, sh, sw):
+    """(Ho, Wo) of a "same"-padded convolution: ceil(H / sh), ceil(W / sw)."""
+    ho, wo = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.load().athena_conv2d_out_shape(H, W, KH, KW, sh, sw, ctypes.byref(ho), ctypes.byref(wo)),
+               "athena_conv2d_out_shape")
+    return ho.value, wo.value
+
+
+def _conv2d_sizes(B, H, W, Cin, Cout, KH, KW, sh, sw):
+    Ho, Wo = -(-H // sh), -(-W // sw)
+    return B * H * W * Cin, B * Ho * Wo * Cout, KH * KW * Cin * Cout
+
+
+def conv2d_fwd(x, w_hwio, out, B, H, W, Cin, Cout, KH, KW, sh, sw, colstats=None):
+    n_in, n_out, n_w = _conv2d_sizes(B, H, W, Cin, Cout, KH, KW, sh, sw)
+    if x.numel() != n_in or out.numel() != n_out or w_hwio.numel() < n_w or x.dtype != w_hwio.dtype or \
+            out.dtype != x.dtype:
+        raise RuntimeError("athena_amd.conv2d_fwd: bad operands")
+    if colstats is not None and (colstats.dtype != torch.float64 or colstats.numel() < 2 * Cout):
+        raise RuntimeError("athena_amd.conv2d_fwd: colstats must be fp64 [2*Cout]")
+    _lib.check(_lib.load().athena_conv2d_fwd(_ptr(x), _ptr(w_hwio), _ptr(out), B, H, W, Cin, Cout, KH, KW, sh, sw,
+                                             dt(x), _ptr(colstats), _stream()), "athena_conv2d_fwd")
+
+
+def conv2d_dgrad(dout, w_hwio, din, B, H, W, Cin, Cout, KH, KW, sh, sw, relu6_out=None):
+    n_in, n_out, n_w = _conv2d_sizes(B, H, W, Cin, Cout, KH, KW, sh, sw)
+    if din.numel() != n_in or dout.numel() != n_out or w_hwio.numel() < n_w or dout.dtype != w_hwio.dtype or \
+            din.dtype != dout.dtype:
+        raise RuntimeError("athena_amd.conv2d_dgrad: bad operands")
+    if relu6_out is not None and (relu6_out.numel() != n_in or relu6_out.dtype != din.dtype):
+        raise RuntimeError("athena_amd.conv2d_dgrad: relu6_out must match din")
+    _lib.check(_lib.load().athena_conv2d_dgrad(_ptr(dout), _ptr(w_hwio), _ptr(din), B, H, W, Cin, Cout, KH, KW, sh, sw,
+                                               dt(dout), _ptr(relu6_out), _stream()), "athena_conv2d_dgrad")
+
+
+def conv2d_wgrad(x, dout, dw, B, H, W, Cin, Cout, KH, KW, sh, sw):
+    n_in, n_out, n_w = _conv2d_sizes(B, H, W, Cin, Cout, KH, KW, sh, sw)
+    if x.numel() != n_in or dout.numel() != n_out or dw.numel() != n_w or dw.dtype != torch.float32 or \
+            x.dtype != dout.dtype:
+        raise RuntimeError("athena_amd.conv2d_wgrad: bad operands")
+    lib = _lib.load()
+    need = int(lib.athena_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, KH, KW, sh, sw, dt(x)))
+    ws = splitk_workspace(x.device)
+    if ws.numel() * ws.element_size() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.athena_conv2d_wgrad(_ptr(x), _ptr(dout), _ptr(dw), B, H, W, Cin, Cout, KH, KW, sh, sw, dt(x),
+                                       ws.data_ptr(), ws.numel() * ws.element_size(), _stream()),
+               "athena_conv2d_wgrad")
+
+
+def im2col(x, col, ldcol, B, H, W, Cin, KH, KW, sh, sw):
+    """col [B*Ho*Wo, ldcol] (zero padding columns beyond KH*KW*Cin) from the NHWC tensor ``x``."""
+    Ho, Wo = -(-H // sh), -(-W // sw)
+    if x.numel() != B * H * W * Cin or col.numel() != B * Ho * Wo * ldcol or ldcol < KH * KW * Cin:
+        raise RuntimeError("athena_amd.im2col: bad operands")
+    _lib.check(_lib.load().athena_im2col(_ptr(x), dt(x), _ptr(col), dt(col), ldcol, B, H, W, Cin, KH, KW, sh, sw,
+                                         _stream()), "athena_im2col")
+
+
+# ------------------------------------------------------------------------------------------ recurrent layers
+RNN_GRU, RNN_LSTM = 0, 1
+
+
+def rnn_workspace(cell, B, H, device):
+    n = int(_lib.load().athena_rnn_workspace_bytes(cell, B, H))
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws):
+    G = 4 if cell == RNN_LSTM else 3
+    if xw.numel() != B * T * G * H or u.numel() < H * G * H or hs_ext.numel() != B * (T + 1) * H or \
+            y.numel() != B * T * H or gates.numel() != B * T * G * H or \
+            any(t.dtype != xw.dtype for t in (u, hs_ext, y, gates)):
+        raise RuntimeError("athena_amd.rnn_fwd: bad operands")
+    if cell == RNN_LSTM and (cs_ext is None or cs_ext.dtype != torch.float32 or cs_ext.numel() != B * (T + 1) * H):
+        raise RuntimeError("athena_amd.rnn_fwd: cs_ext must be fp32 [B, T+1, H]")
+    if cell == RNN_GRU and (rh is None or rh.numel() != B * T * H or rh.dtype != xw.dtype):
+        raise RuntimeError("athena_amd.rnn_fwd: rh must be [B, T, H]")
+    if b_rec is not None and (b_rec.dtype != torch.float32 or b_rec.numel() != G * H):
+        raise RuntimeError("athena_amd.rnn_fwd: b_rec must be fp32 [G*H]")
+    _lib.check(_lib.load().athena_rnn_fwd(cell, _ptr(xw), _ptr(u), _ptr(b_rec), _ptr(hs_ext), _ptr(cs_ext), _ptr(y),
+                                          _ptr(gates), _ptr(rh), B, T, H, dt(xw), ws.data_ptr(),
+                                          ws.numel() * ws.element_size(), _stream()), "athena_rnn_fwd")
+
+
+def rnn_bwd(cell, dy, u, hs_ext, cs_ext, gates, rh, dxw, dhu_ext, B, T, H, ws):
+    G = 4 if cell == RNN_LSTM else 3
+    if dy.numel() != B * T * H or u.numel() < H * G * H or hs_ext.numel() != B * (T + 1) * H or \
+            gates.numel() != B * T * G * H or dxw.numel() != B * T * G * H or dhu_ext.numel() != B * (T + 1) * G * H or \
+            any(t.dtype != dy.dtype for t in (u, hs_ext, gates, dxw, dhu_ext)):
+        raise RuntimeError("athena_amd.rnn_bwd: bad operands")
+    _lib.check(_lib.load().athena_rnn_bwd(cell, _ptr(dy), _ptr(u), _ptr(hs_ext), _ptr(cs_ext), _ptr(gates), _ptr(rh),
+                                          _ptr(dxw), _ptr(dhu_ext), B, T, H, dt(dy), ws.data_ptr(),
+                                          ws.numel() * ws.element_size(), _stream()), "athena_rnn_bwd")
+
+
 # ------------------------------------------------------------------------------------------ PE / embedding
 def add_pe_dropout(x, pe, B, T, d, xscale, drop_p, rng_state, site, y):
     lib = _lib.load()

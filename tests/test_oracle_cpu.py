@@ -237,3 +237,77 @@ def test_mpc_loss_oracle_against_explicit_loops():
                     total += abs(float(target[b, t, c]) - float(logits[b, t, c]))
     got = om.mpc_loss(logits, {"output": target.reshape(B, Tp * 2, 3), "input": masked.reshape(B, Tp * 2, 3, 1)}, length)
     assert abs(float(got) - total / (B * Tp)) < 1e-12
+
+
+# ---------------------------------------------------------------- DeepSpeech oracle (oracle/deep_speech.py)
+def test_oracle_gru_and_lstm_layers_match_torch_nn():
+    """The oracle's Keras-order GRU (reset_after) and LSTM against torch.nn.GRU / torch.nn.LSTM, which
+    implement the same cell equations with the gates in another order (GRU: r, z, n; LSTM: i, f, g, o)
+    and two bias vectors."""
+    from oracle import deep_speech as ods
+    g = torch.Generator().manual_seed(5)
+    B, T, K, H = 3, 7, 6, 5
+    x = torch.randn(B, T, K, generator=g, dtype=torch.float64)
+    # GRU
+    W = torch.randn(K, 3 * H, generator=g, dtype=torch.float64) * 0.5
+    U = torch.randn(H, 3 * H, generator=g, dtype=torch.float64) * 0.5
+    b = torch.randn(2, 3 * H, generator=g, dtype=torch.float64) * 0.3
+    ref = torch.nn.GRU(K, H, batch_first=True).double()
+    perm = torch.cat([torch.arange(H, 2 * H), torch.arange(0, H), torch.arange(2 * H, 3 * H)])   # keras z r h -> r z n
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(W.t()[perm])
+        ref.weight_hh_l0.copy_(U.t()[perm])
+        ref.bias_ih_l0.copy_(b[0][perm])
+        ref.bias_hh_l0.copy_(b[1][perm])
+    want, _ = ref(x)
+    got = ods.gru_layer(x, W, U, b)
+    assert float((got - want).abs().max()) < 1e-12
+    # LSTM (same gate order; torch adds its two biases)
+    W = torch.randn(K, 4 * H, generator=g, dtype=torch.float64) * 0.5
+    U = torch.randn(H, 4 * H, generator=g, dtype=torch.float64) * 0.5
+    b = torch.randn(4 * H, generator=g, dtype=torch.float64) * 0.3
+    ref = torch.nn.LSTM(K, H, batch_first=True).double()
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(W.t())
+        ref.weight_hh_l0.copy_(U.t())
+        ref.bias_ih_l0.copy_(b)
+        ref.bias_hh_l0.zero_()
+    want, _ = ref(x)
+    got = ods.lstm_layer(x, W, U, b)
+    assert float((got - want).abs().max()) < 1e-12
+
+
+def test_oracle_conv2d_same_matches_explicit_sum():
+    """"same" padding with even and odd sizes and both stride pairs of the model, against the defining
+    sum written out with loops."""
+    from oracle import deep_speech as ods
+    g = torch.Generator().manual_seed(6)
+    for (H, W, kh, kw, sh, sw) in ((9, 6, 5, 3, 2, 2), (8, 5, 4, 3, 2, 1), (7, 7, 41, 11, 2, 2)):
+        x = torch.randn(2, H, W, 2, generator=g, dtype=torch.float64)
+        w = torch.randn(kh, kw, 2, 3, generator=g, dtype=torch.float64)
+        got = ods.conv2d_same(x, w, (sh, sw))
+        Ho, Wo = -(-H // sh), -(-W // sw)
+        assert tuple(got.shape) == (2, Ho, Wo, 3)
+        ph, _ = ods.same_pad(H, kh, sh)
+        pw, _ = ods.same_pad(W, kw, sw)
+        want = torch.zeros(2, Ho, Wo, 3, dtype=torch.float64)
+        for ho in range(Ho):
+            for wo in range(Wo):
+                for a in range(kh):
+                    for c in range(kw):
+                        h, v = sh * ho - ph + a, sw * wo - pw + c
+                        if 0 <= h < H and 0 <= v < W:
+                            want[:, ho, wo] += x[:, h, v] @ w[a, c]
+        assert float((got - want).abs().max()) < 1e-10
+
+
+def test_oracle_deep_speech_forward_shapes_and_loss():
+    from oracle import deep_speech as ods
+    from oracle import model as om
+    cfg = {"conv_filters": 8, "rnn_hidden_size": 16, "num_rnn_layers": 2, "rnn_type": "gru"}
+    p = ods.init_params(cfg, 10, 12, seed=2)
+    s = om.make_samples(2, 37, 10, 12, 3, seed=3, full_length=False, dtype=torch.float64)
+    loss, logits, grads = ods.loss_and_grads(p, s, cfg)
+    assert tuple(logits.shape) == (2, 10, 12) and torch.isfinite(loss) and float(loss) > 0
+    assert set(grads) == {k for k in p if not k.endswith(("moving_mean", "moving_variance"))}
+    assert all(torch.isfinite(v).all() for v in grads.values())
