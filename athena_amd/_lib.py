@@ -135,7 +135,7 @@ _SIGNATURES = {
     "athena_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 10 + [_P, c_int64, _S]),
     "athena_im2col": (c_int, [_P, c_int, _P, c_int, c_int] + [c_int] * 8 + [_S]),
     "athena_rnn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
-    "athena_rnn_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
+    "athena_rnn_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
     "athena_rnn_bwd": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
     "athena_add_pe_dropout": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_uint32, _P, _S]),
     "athena_dropout_bwd": (c_int, [_P, c_long, c_int, c_float, c_float, _P, c_uint32, _P, _P, _S]),

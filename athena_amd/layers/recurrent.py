@@ -75,7 +75,7 @@ class RNNParams(_Bound):
             store.register(name + ".bias", (g,), lstm_bias())
         else:
             store.register(name + ".bias", (2, g), constant(0.0))
-        self.k_shadow = self.k_shadow_t = self.u_shadow = None
+        self.k_shadow = self.k_shadow_t = self.u_shadow = self.u_shadow_t = None
 
     def bind(self):
         self._bind_param("kernel", self.vname + ".kernel")
@@ -83,7 +83,7 @@ class RNNParams(_Bound):
         self._bind_param("bias", self.vname + ".bias")
         if self.store.shadow is not None:
             self.k_shadow, self.k_shadow_t = self.store.shadow_views(self.vname + ".kernel")
-            self.u_shadow, _ = self.store.shadow_views(self.vname + ".recurrent_kernel")
+            self.u_shadow, self.u_shadow_t = self.store.shadow_views(self.vname + ".recurrent_kernel")
 
     def bias_views(self):
         """(input bias, recurrent bias or None, their gradient views)."""
@@ -240,7 +240,8 @@ class RnnBnFn(torch.autograd.Function):
         y = torch.empty((B, T, H), dtype=cd, device=dev)
         gates = torch.empty((B, T, G * H), dtype=cd, device=dev)
         ws = ops.rnn_workspace(cell, B, H, dev)
-        ops.rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws)
+        ops.rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws,
+                    u_t=p.u_shadow_t if cd == torch.bfloat16 else None)
         mr = None
         if training:
             stats = torch.empty(2 * H, dtype=torch.float64, device=dev)

@@ -667,7 +667,7 @@ def rnn_workspace(cell, B, H, device):
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
-def rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws):
+def rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws, u_t=None):
     G = 4 if cell == RNN_LSTM else 3
     if xw.numel() != B * T * G * H or u.numel() < H * G * H or hs_ext.numel() != B * (T + 1) * H or \
             y.numel() != B * T * H or gates.numel() != B * T * G * H or \
@@ -679,7 +679,9 @@ def rnn_fwd(cell, xw, u, b_rec, hs_ext, cs_ext, y, gates, rh, B, T, H, ws):
         raise RuntimeError("athena_amd.rnn_fwd: rh must be [B, T, H]")
     if b_rec is not None and (b_rec.dtype != torch.float32 or b_rec.numel() != G * H):
         raise RuntimeError("athena_amd.rnn_fwd: b_rec must be fp32 [G*H]")
-    _lib.check(_lib.load().athena_rnn_fwd(cell, _ptr(xw), _ptr(u), _ptr(b_rec), _ptr(hs_ext), _ptr(cs_ext), _ptr(y),
+    if u_t is not None and (u_t.dtype != xw.dtype or u_t.numel() < G * H * H):
+        raise RuntimeError("athena_amd.rnn_fwd: u_t must be the transposed recurrent kernel [G*H, H]")
+    _lib.check(_lib.load().athena_rnn_fwd(cell, _ptr(xw), _ptr(u), _ptr(u_t), _ptr(b_rec), _ptr(hs_ext), _ptr(cs_ext), _ptr(y),
                                           _ptr(gates), _ptr(rh), B, T, H, dt(xw), ws.data_ptr(),
                                           ws.numel() * ws.element_size(), _stream()), "athena_rnn_fwd")
 

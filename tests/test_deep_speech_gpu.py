@@ -122,7 +122,8 @@ def test_batchnorm_without_relu6(cd):
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
-@pytest.mark.parametrize("shape", [(3, 9, 16, 24), (2, 33, 40, 64)], ids=["short", "longer"])
+@pytest.mark.parametrize("shape", [(3, 9, 16, 24), (2, 33, 40, 64), (37, 5, 24, 1680)],
+                         ids=["short", "longer", "two-row-blocks-wide"])
 def test_recurrent_layer_kernels(cell, cd, shape):
     """athena_rnn_fwd / athena_rnn_bwd (the serial part) with the projections done as plain matrix
     products here, against the oracle's layer under autograd: outputs, input gradient and the three
@@ -154,6 +155,15 @@ def test_recurrent_layer_kernels(cell, cd, shape):
     ws = ops.rnn_workspace(code, B, H, dev())
     ops.rnn_fwd(code, xw, ud, b_rec, hs, cs, y, gates, rh, B, T, H, ws)
     assert_close(y, ref.detach(), tol, "rnn outputs")
+    if cd == torch.bfloat16:
+        # with the transposed copy of the recurrent kernel a step is one launch (product and gates together)
+        y2, hs2, gates2 = torch.empty_like(y), torch.full_like(hs, 3.0), torch.empty_like(gates)
+        cs2 = torch.full_like(cs, 3.0) if cs is not None else None
+        rh2 = torch.empty_like(rh) if rh is not None else None
+        ops.rnn_fwd(code, xw, ud, b_rec, hs2, cs2, y2, gates2, rh2, B, T, H, ws, u_t=ud.t().contiguous())
+        assert_close(y2, ref.detach(), tol, "rnn outputs, one launch per step")
+        assert_close(gates2, gates, 2e-2, "gates of the two forward paths")
+        assert float(hs2[:, 0].abs().max()) == 0.0 and torch.equal(hs2[:, 1:], y2)
     assert float(hs[:, 0].abs().max()) == 0.0 and torch.equal(hs[:, 1:], y)
     dxw = torch.empty((B, T, G * H), dtype=cd, device=dev())
     dhu = torch.full((B, T + 1, G * H), 5.0, dtype=cd, device=dev())
