@@ -5,6 +5,8 @@
 gradient buffer is averaged across ranks with bucketed all-reduces on RCCL
 (``torch.distributed`` backend "nccl") in place of ``hvd.DistributedGradientTape``.
 """
+import contextlib
+import gc
 import logging
 import os
 
@@ -192,6 +194,23 @@ class BaseSolver:
 _CAPTURE_MODE = "thread_local"
 
 
+@contextlib.contextmanager
+def _capture(graph, pool):
+    """Record into ``graph``.  The garbage collector stays off while the stream is capturing: a
+    collection in the middle of a recording may run the destructor of an evicted step's graphs (they
+    sit in reference cycles with their solver), and releasing a graph and its memory blocks from
+    inside another graph's capture aborts the process."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def _shape_key(samples):
     return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(samples.items()))
 
@@ -216,14 +235,14 @@ class _GraphStep:
         # the recorded forward pass always starts by rebuilding the bf16 weight copies: whether the
         # host flag happens to be set while recording must not decide what every replay does
         solver.model.store.shadows_dirty = True
-        with torch.cuda.graph(self.graph, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE):
+        with _capture(self.graph, solver._graph_pool()):
             self.loss, self.metrics = solver._forward_backward(self.inputs)
             if not split:
                 solver._update(1.0)
         self.update_graph = None
         if split:
             self.update_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.update_graph, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE):
+            with _capture(self.update_graph, solver._graph_pool()):
                 solver._update(1.0 / solver.world_size)
         # the deferred scorers queued while recording become templates
         self.templates = []
@@ -269,7 +288,7 @@ class _PipelinedGraphStep:
         store.collect_cuts = True
         store.shadows_dirty = True          # the refresh is always part of the recorded forward pass
         try:
-            with torch.cuda.graph(g0, pool=solver._graph_pool(), capture_error_mode=_CAPTURE_MODE), \
+            with _capture(g0, solver._graph_pool()), \
                     ops.bf16_grad_handover():
                 outputs = solver.model(self.inputs, training=True)
                 self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
@@ -287,17 +306,17 @@ class _PipelinedGraphStep:
         up, g_up = cuts["memory"], g_mem
         for tag in reversed(enc_cuts):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+            with _capture(g, g0.pool()):
                 (g_dn,) = torch.autograd.grad([up], [cuts[tag]], [g_up], retain_graph=True)
             self.graphs.append(g)
             up, g_up = cuts[tag], g_dn
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+        with _capture(g, g0.pool()):
             torch.autograd.backward([up, cuts["y_net"]], [g_up, g_y])
         self.graphs.append(g)
         assert len(self.graphs) == len(self.ranges)
         self.update_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.update_graph, pool=g0.pool(), capture_error_mode=_CAPTURE_MODE):
+        with _capture(self.update_graph, g0.pool()):
             solver._update(1.0 / max(solver.world_size, 1))
         self._keep = (cuts, g_mem, g_y, up, g_up)          # the graphs' buffers must outlive them
         self.templates = []
