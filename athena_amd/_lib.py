@@ -148,6 +148,9 @@ _SIGNATURES = {
     "athena_ctc_loss_fwd_static": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_ctc_loss_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float,
                                     _P, c_int, _P, c_size_t, _S]),
+    "athena_ctc_loss_fwd_bwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_float,
+                                        _P, c_int, _P, c_size_t, _S]),
+    "athena_rescale_unless": (c_int, [_P, c_long, c_int, _P, c_float, _S]),
     "athena_ce_loss_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, _S]),
     "athena_ce_loss_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, c_float, _P, c_int, _S]),
     "athena_group_sum": (c_int, [_P, c_int, c_int, c_float, _P, _S]),

@@ -4,17 +4,22 @@
 //
 // CTC is three kernels:
 //   ctc_fwd    : the lattice workgroups (one per sample: alpha and beta recursions in two
-//                wavefronts, states in registers) and the row workgroups (logsumexp of one logits
-//                row each) in one launch, so the serial recursion overlaps the streaming pass
-//   ctc_finish : per-sample loss from the lattice path sum and the row normalisers
-//   ctc_grad   : one workgroup per row: posterior = normalise(alpha+beta) scattered by class
-//                into an LDS accumulator, then grad = scale * (softmax - occupancy) streamed out
+//                wavefronts, states in registers, probabilities in double precision) and the row
+//                workgroups (logsumexp of one logits row each) in one launch, so the serial
+//                recursion overlaps the streaming pass
+//   ctc_post   : one wave per logits row: the state posterior alpha*beta, normalised, as a short
+//                list (blank, label 1, label 2, ...); one wave per sample: the loss from the
+//                lattice path sum and the row normalisers
+//   ctc_grad   : one workgroup per row: the posterior list scattered by class into an LDS
+//                accumulator, then grad = scale * (softmax - occupancy) streamed out
 #include "common.h"
 
 #include <mutex>
 
 #define CTC_LOGZERO (-1e30f)
 #define CTC_MAX_R 16            // lattice states per lane: supports 2U+1 <= 1024
+#define CTC_MAX_U (64 * CTC_MAX_R / 2)   // label positions
+#define CTC_EMIS_PAD 16         // rows of padding in front of and behind the emission table
 #define CTC_LOG2E 1.4426950408889634f
 #define CTC_LN2 0.6931471805599453
 
@@ -23,7 +28,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // states per lane the lattice kernel is instantiated for
 static int ctc_launch_r(int S) {
     const int R = (S + 63) / 64;
-    static const int sizes[] = {1, 2, 3, 4, 5, 7, 10, CTC_MAX_R};
+    static const int sizes[] = {2, 4, 6, 8, 12, CTC_MAX_R};    // even: a lane then holds whole (blank, label) pairs
     for (int v : sizes)
         if (R <= v) return v;
     return CTC_MAX_R;
@@ -32,32 +37,47 @@ static int ctc_launch_r(int S) {
 struct CtcWorkspace {
     float* lse;      // [B*T]     natural-log normaliser of each row (softmax of the gradient)
     float* nrm;      // [B*T]     lse - logit[blank]: the normaliser relative to the blank logit
-    float* alpha;    // [B*T*Sp]  log2 alpha up to a per-(b,t) constant (emission at t included)
-    float* beta;     // [B*T*Sp]  log2 beta  up to a per-(b,t) constant (emission at t excluded)
+    double* alpha;   // [B*T*Sp]  alpha up to a per-(b,t) power of two (emission at t included)
+    double* beta;    // [B*T*Sp]  beta  up to a per-(b,t) power of two (emission at t excluded)
+    double* emis;    // [B*T*Sp/2] emission of every label state relative to blank (0 beyond the last label)
+    float* occ;      // [B*T*Up]  state posterior of a row: [0] all blank states, [1+u] label u
+    int32_t* first;  // [B*U]     first label position with the same class (-1: the class is the blank)
     double* ll;      // [B]       log2 of the path sum over blank-relative emissions (-inf: no path)
-    int32_t* flags;  // [B]       1: no alignment fits; alpha / beta then hold TensorFlow's leaky lattice
+    int32_t* flags;  // [B]       1: no alignment fits; occ then holds TensorFlow's leaky lattice
     int Sp;          // row pitch of alpha / beta: 64 * states per lane
+    int Up;          // row pitch of occ: U + 1 rounded up to 4
 };
 
 static size_t ctc_ws_layout(int B, int T, int U, void* base, CtcWorkspace* ws) {
     const int Sp = 64 * ctc_launch_r(2 * U + 1);
+    const int Up = (U + 1 + 3) / 4 * 4;
     size_t off = 0;
     char* p = (char*)base;
     size_t n_row = align_up(sizeof(float) * (size_t)B * T, 256);
-    size_t n_lat = align_up(sizeof(float) * (size_t)B * T * Sp, 256);
+    size_t n_lat = align_up(sizeof(double) * (size_t)B * T * Sp, 256);
     if (ws) ws->lse = (float*)(p + off);
     off += n_row;
     if (ws) ws->nrm = (float*)(p + off);
     off += n_row;
-    if (ws) ws->alpha = (float*)(p + off);
+    if (ws) ws->alpha = (double*)(p + off);
     off += n_lat;
-    if (ws) ws->beta = (float*)(p + off);
+    if (ws) ws->beta = (double*)(p + off);
     off += n_lat;
+    // (the lattice prefetches a few rows past either end of a sample's part)
+    if (ws) ws->emis = (double*)(p + off) + (size_t)CTC_EMIS_PAD * (Sp / 2);
+    off += align_up(sizeof(double) * ((size_t)B * T + 2 * CTC_EMIS_PAD) * (Sp / 2), 256);
+    if (ws) ws->occ = (float*)(p + off);
+    off += align_up(sizeof(float) * (size_t)B * T * Up, 256);
+    if (ws) ws->first = (int32_t*)(p + off);
+    off += align_up(sizeof(int32_t) * (size_t)B * (U > 0 ? U : 1), 256);
     if (ws) ws->ll = (double*)(p + off);
     off += align_up(sizeof(double) * (size_t)B, 256);
     if (ws) ws->flags = (int32_t*)(p + off);
     off += align_up(sizeof(int32_t) * (size_t)B, 256);
-    if (ws) ws->Sp = Sp;
+    if (ws) {
+        ws->Sp = Sp;
+        ws->Up = Up;
+    }
     return off;
 }
 
@@ -171,17 +191,20 @@ __device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V
 // fp32 rows of at most CTC_ROW_REGS * 1024 columns with ld % 4 == 0: the whole row is fetched into
 // registers before anything depends on it (all loads of a thread in flight at once instead of one
 // per trip of an online loop), then maximum, first arg-max and the sum of exponentials relative to
-// the workgroup's maximum are taken from the registers.  Columns V .. ld-1 are padding and masked.
+// the workgroup's maximum are taken from the registers, which stay with the caller (columns
+// V .. ld-1 are padding and come back as -inf).  Two workgroup reductions: the maximum, then the
+// sum and the arg-max candidates together.
 #define CTC_ROW_REGS 8
-__device__ __forceinline__ void row_max_sum_arg_regs(const float* __restrict__ row, int V, int ld, float& m_out,
-                                                     float& s_out, int& arg_out, float* red) {
-    float4 x[CTC_ROW_REGS];
+__device__ __forceinline__ void row_regs_load(const float* __restrict__ row, int ld, float4 (&x)[CTC_ROW_REGS]) {
 #pragma unroll
     for (int i = 0; i < CTC_ROW_REGS; ++i) {
         const int c = (i * 256 + threadIdx.x) * 4;
         x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         if (c < ld) x[i] = *(const float4*)(row + c);
     }
+}
+__device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V, float& m_out, float& s_out,
+                                               int& arg_out, float* red) {
     float m = -INFINITY;
     int idx = 0x7fffffff;
 #pragma unroll
@@ -206,295 +229,522 @@ __device__ __forceinline__ void row_max_sum_arg_regs(const float* __restrict__ r
         for (int i = 0; i < CTC_ROW_REGS; ++i)
             s += __expf(x[i].x - gm) + __expf(x[i].y - gm) + __expf(x[i].z - gm) + __expf(x[i].w - gm);
     }
-    s_out = block_sum(s, red);
-    const float cand = (m == gm && idx != 0x7fffffff) ? -(float)idx : -INFINITY;
-    const float best = block_max(cand, red);
+    // smallest column among the threads that saw the maximum (column indices are exact in fp32)
+    float cand = (m == gm && idx != 0x7fffffff) ? -(float)idx : -INFINITY;
+    s = wave_sum(s);
+    cand = wave_max(cand);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        red[w] = s;
+        red[8 + w] = cand;
+    }
+    __syncthreads();
+    s_out = (red[0] + red[1]) + (red[2] + red[3]);
+    const float best = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
     arg_out = best == -INFINITY ? 0 : (int)(-best);
     m_out = gm;
 }
 
-// ---------------------------------------------------------------- lattice arithmetic (log2 domain)
-// log2(2^a + 2^b + 2^c) and log2(2^a + 2^b) on the raw exp2 / log2 units: the largest term
-// contributes exactly 1, so one exponential fewer than terms
-__device__ __forceinline__ float lse3_2(float a, float b, float c) {
-    const float hi = fmaxf(a, fmaxf(b, c));
-    const float lo = fminf(a, fminf(b, c));
-    const float md = __builtin_amdgcn_fmed3f(a, b, c);
-    return hi + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(md - hi) + __builtin_amdgcn_exp2f(lo - hi));
-}
-__device__ __forceinline__ float lse2_2(float a, float b) {
-    return fmaxf(a, b) + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
-}
+// ---------------------------------------------------------------- lattice arithmetic
+// The recursions run on probabilities (not their logarithms) in double precision: a step is two
+// additions and one multiplication per state instead of a log-sum-exp of three terms, and the only
+// transcendental left is the exponential of the emission, which does not sit on the dependency
+// chain.  Every fourth step the state vector is scaled by a power of two (exact) so that its
+// largest element stays near 1; an emission lies in [2^-126, 2^128], so nothing can overflow
+// between two scalings, and what underflows is below 2^-500 of the row's largest state.  A sample
+// whose path sum still comes out as zero or not finite is handed to the slow path of ctc_post, which
+// works on logarithms.
 
-// value held by the previous / next lane of the wave (``fill`` where there is none): a single DPP
-// move (wave_shr:1 / wave_shl:1) instead of a trip through the LDS crossbar
-__device__ __forceinline__ float lane_prev(float v, float fill) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+// value held by the previous / next lane of the wave (0 where there is none): DPP moves
+// (wave_shr:1 / wave_shl:1, lanes without a source read 0) on the two halves instead of a trip
+// through the LDS crossbar
+__device__ __forceinline__ double lane_prev_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float lane_next(float v, float fill) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+__device__ __forceinline__ double lane_next_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 template <int CTRL>
-__device__ __forceinline__ float dpp_max(float v) {
-    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+__device__ __forceinline__ int dpp_imax(int v) {
+    return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false));
 }
 // maximum over the wave: four DPP steps inside each row of 16 lanes (quad swaps, half mirror,
 // mirror), then the four row results through scalar registers
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    v = dpp_max<0xB1>(v);       // quad_perm [1,0,3,2]
-    v = dpp_max<0x4E>(v);       // quad_perm [2,3,0,1]
-    v = dpp_max<0x141>(v);      // row_half_mirror
-    v = dpp_max<0x140>(v);      // row_mirror
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+__device__ __forceinline__ int wave_imax_dpp(int v) {
+    v = dpp_imax<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_imax<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_imax<0x141>(v);     // row_half_mirror
+    v = dpp_imax<0x140>(v);     // row_mirror
+    const int r0 = __builtin_amdgcn_readlane(v, 0);
+    const int r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32);
+    const int r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+// The high words of non-negative doubles order like the doubles.  From the largest high word of a
+// set: the power of two that brings its owner into [1, 2) (0 if the set is all zero or not finite).
+__device__ __forceinline__ int scale_exponent(int max_hi) {
+    const int e = (max_hi >> 20) & 0x7ff;
+    return (e == 0 || e == 0x7ff) ? 0 : e - 1023;
 }
 
-// R consecutive floats per lane, as the widest stores the count allows
+// R consecutive doubles per lane, as the widest stores the count allows
 template <int R>
-__device__ __forceinline__ void store_states(float* __restrict__ dst, const float (&a)[R]) {
-    if constexpr (R % 4 == 0) {
+__device__ __forceinline__ void store_states(double* __restrict__ dst, const double (&a)[R]) {
+    if constexpr (R % 2 == 0) {
 #pragma unroll
-        for (int r = 0; r < R; r += 4) *(float4*)(dst + r) = make_float4(a[r], a[r + 1], a[r + 2], a[r + 3]);
-    } else if constexpr (R % 2 == 0) {
-#pragma unroll
-        for (int r = 0; r < R; r += 2) *(float2*)(dst + r) = make_float2(a[r], a[r + 1]);
+        for (int r = 0; r < R; r += 2) *(double2*)(dst + r) = make_double2(a[r], a[r + 1]);
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) dst[r] = a[r];
     }
 }
 
-// ---------------------------------------------------------------- ctc forward
-// One launch, two kinds of workgroup.
-//   blockIdx <  B : the lattice of sample b.  Wave 0 runs the alpha recursion forward in time,
-//                   wave 1 the beta recursion backward; each lane owns R consecutive states in
-//                   registers and gets its neighbours by DPP.  Emissions are read straight from
-//                   the logits relative to the blank logit of the row,
-//                       e[t][s] = (logit[t][ext[s]] - logit[t][blank]) * log2(e),
-//                   so the lattice does not wait for the row normalisers and its values stay
-//                   small wherever blank or the label dominates; the per-row constant
-//                   lse - logit[blank] is summed back by ctc_finish.  Every fourth step the state
-//                   vector is shifted by its maximum (kept in a double) to hold fp32 resolution.
-//   blockIdx >= B : one logits row each: logsumexp over V.
-// The lattice workgroups are dispatched first and run for the length of the recursion while the
-// rest of the chip streams the rows.
-template <typename T, int R>
-__global__ __launch_bounds__(256) void ctc_fwd_kernel(const T* __restrict__ logits, int ldl,
+// ---------------------------------------------------------------- ctc rows
+template <typename TL>
+struct CtcRowVec;
+template <>
+struct CtcRowVec<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *(const float4*)p; }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <>
+struct CtcRowVec<bf16_t> {
+    uint2 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const uint2*)p; }
+    __device__ __forceinline__ float get(int i) const {
+        const uint32_t w = i < 2 ? v.x : v.y;
+        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+};
+template <typename TG>
+__device__ __forceinline__ void ctc_store4(TG* p, float a, float b, float c, float d);
+template <>
+__device__ __forceinline__ void ctc_store4<float>(float* p, float a, float b, float c, float d) {
+    *(float4*)p = make_float4(a, b, c, d);
+}
+template <>
+__device__ __forceinline__ void ctc_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+    union { bf16_t h[4]; uint2 u; } pk;
+    pk.h[0] = (bf16_t)a; pk.h[1] = (bf16_t)b; pk.h[2] = (bf16_t)c; pk.h[3] = (bf16_t)d;
+    *(uint2*)p = pk.u;
+}
+
+template <typename TG>
+__device__ __forceinline__ void ctc_store1(TG* p, float a) { *p = (TG)a; }
+
+// First CTC launch: one workgroup per logits row.
+//   * logsumexp of the row (lse, and nrm = lse - logit[blank]) and its first arg-max (the greedy path
+//     of the accuracy metric, reference athena/metrics.py:121-132)
+//   * the emissions the lattice will need, gathered while the row is at hand: one double per label,
+//     p[u] = exp(logit[label u] - logit[blank]) (0 beyond the sample's last label; a blank state has
+//     factor 1 by construction), so that the recursion reads R/2 consecutive doubles per lane
+//     instead of gathering 2U+1 cache lines per step
+//   * kGrad: the dense part of the gradient, gscale * softmax(row), written while the row is in
+//     registers (the padding columns and the rows beyond logit_length as zeros); ctc_post subtracts
+//     the occupancy at the few columns that have one
+template <typename T, typename TG, bool kGrad>
+__global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logits, int ldl,
                                                       const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ label_len,
-                                                      const int32_t* __restrict__ logit_len, int B, int T_, int V,
-                                                      int U, int blank, float* __restrict__ lse,
-                                                      float* __restrict__ nrm, float* __restrict__ alpha,
-                                                      float* __restrict__ beta, double* __restrict__ ll,
-                                                      int32_t* __restrict__ argmax) {
+                                                      const int32_t* __restrict__ logit_len, int T_, int V, int U,
+                                                      int blank, int Sp, float* __restrict__ lse,
+                                                      float* __restrict__ nrm, double* __restrict__ emis,
+                                                      int32_t* __restrict__ argmax,
+                                                      int32_t* __restrict__ first, float gscale,
+                                                      TG* __restrict__ grad) {
     __shared__ float red[32];
-    if ((int)blockIdx.x >= B) {
-        const int row = blockIdx.x - B;
-        const int b = row / T_, t = row - b * T_;
-        if (t >= logit_len[b]) return;
-        const T* lr = logits + (long)row * ldl;
-        float m, s;
-        int am = 0;
-        bool in_regs = false;
-        if constexpr (sizeof(T) == 4) in_regs = ldl <= CTC_ROW_REGS * 1024 && (ldl & 3) == 0;
-        if (in_regs) row_max_sum_arg_regs((const float*)lr, V, ldl, m, s, am, red);     // uniform branches
-        else if (argmax) row_max_sum_arg<T>(lr, V, m, s, am, red);
-        else row_max_sum<T>(lr, V, m, s, red);
-        if (threadIdx.x == 0) {
-            const float ls = __logf(s);
-            lse[row] = m + ls;
-            nrm[row] = (m - to_f32<T>(lr[blank])) + ls;
-            if (argmax) argmax[row] = am;
+    __shared__ int32_t labs[CTC_MAX_U];
+    const int row = blockIdx.x;
+    const int b = row / T_, t = row - b * T_;
+    if (t == 0) {
+        // labels that repeat share one logits column: ctc_post sums their occupancies at the first of them
+        for (int u = threadIdx.x; u < U; u += 256) labs[u] = labels[(long)b * U + u];
+        __syncthreads();
+        for (int u = threadIdx.x; u < U; u += 256) {
+            const int c = labs[u];
+            int f = u;
+            for (int u2 = u - 1; u2 >= 0; --u2) f = labs[u2] == c ? u2 : f;
+            first[(long)b * U + u] = c == blank ? -1 : f;
+        }
+    }
+    if (t >= logit_len[b]) {
+        if constexpr (kGrad) {
+            TG* gr = grad + (long)row * ldl;
+            for (int c = threadIdx.x * 4; c < ldl; c += 1024) ctc_store4<TG>(gr + c, 0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
-    if (threadIdx.x >= 128) return;
-    // the recursion is one long dependency chain: let it issue ahead of the row workgroups that
-    // share its SIMD
-    __builtin_amdgcn_s_setprio(3);
+    const T* lr = logits + (long)row * ldl;
+    bool in_regs = false;
+    if constexpr (sizeof(T) == 4) in_regs = ldl <= CTC_ROW_REGS * 1024;
+    float4 x[CTC_ROW_REGS];
+    if constexpr (sizeof(T) == 4) {
+        if (in_regs) row_regs_load((const float*)lr, ldl, x);
+    }
+    // the emissions are requested behind the row, so they arrive during its reductions
+    const int L = min(max(label_len[b], 0), U);
+    const int Lp = Sp / 2;
+    constexpr int EP = CTC_MAX_U / 256;
+    float ev[EP];
+#pragma unroll
+    for (int i = 0; i < EP; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        ev[i] = 0.f;
+        if (u < L) {
+            int c = labels[(long)b * U + u];
+            if (c < 0 || c >= V) c = blank;
+            ev[i] = to_f32<T>(lr[c]);
+        }
+    }
+    const float xb = to_f32<T>(lr[blank]);
+    float m, sum;
+    int am = 0;
+    if (in_regs) {
+        if constexpr (sizeof(T) == 4) row_regs_stats(x, V, m, sum, am, red);
+    } else if (argmax) {
+        row_max_sum_arg<T>(lr, V, m, sum, am, red);
+    } else {
+        row_max_sum<T>(lr, V, m, sum, red);
+    }
+    const float l = m + __logf(sum);
+    if (threadIdx.x == 0) {
+        lse[row] = l;
+        nrm[row] = l - xb;
+        if (argmax) argmax[row] = am;
+    }
+#pragma unroll
+    for (int i = 0; i < EP; ++i) {
+        const int u = threadIdx.x + 256 * i;
+        if (u < Lp) {
+            // 2^e over the whole double range: the fraction on the fp32 unit, the integer part as exponent
+            const float e = fminf(fmaxf((ev[i] - xb) * CTC_LOG2E, -2000.f), 2000.f);
+            const float ei = floorf(e);
+            emis[(long)row * Lp + u] = u < L ? ldexp((double)__builtin_amdgcn_exp2f(e - ei), (int)ei) : 0.0;
+        }
+    }
+    if constexpr (kGrad) {
+        TG* gr = grad + (long)row * ldl;
+        if (in_regs) {
+            if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                for (int i = 0; i < CTC_ROW_REGS; ++i) {
+                    const int c = (i * 256 + threadIdx.x) * 4;
+                    // masked columns hold -inf: their exponential is the zero the padding wants
+                    if (c < ldl)
+                        ctc_store4<TG>(gr + c, gscale * __expf(x[i].x - l), gscale * __expf(x[i].y - l),
+                                       gscale * __expf(x[i].z - l), gscale * __expf(x[i].w - l));
+                }
+            }
+        } else {
+            for (int c = threadIdx.x * 4; c < ldl; c += 1024) {
+                CtcRowVec<T> v;
+                v.load(lr + c);
+                float g[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = (c + k < V) ? gscale * __expf(v.get(k) - l) : 0.f;
+                ctc_store4<TG>(gr + c, g[0], g[1], g[2], g[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ctc lattice
+// Second CTC launch: one workgroup of two waves per sample.  Wave 0 runs the alpha recursion forward
+// in time, wave 1 the beta recursion backward; each lane owns R consecutive states in registers and
+// gets its neighbours by DPP.  The emissions come from the table ctc_row_kernel left, relative to the
+// blank logit of their row, so a blank state costs no multiplication; the per-row constant
+// lse - logit[blank] is summed back by ctc_post.
+// One LDS word read or written by an instruction of its own, with the wait inside the statement:
+// the counters two waves talk through.  (A volatile access would do, but the compiler follows each
+// with a wait for every outstanding memory operation of the wave, emission prefetches included.)
+__device__ __forceinline__ int lds_peek(const int* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(v)
+                 : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const int*)p)
+                 : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_poke(int* p, int v) {
+    asm volatile("ds_write_b32 %0, %1"
+                 :
+                 : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) int*)p), "v"(v)
+                 : "memory");
+}
+
+// R consecutive doubles per lane, as the widest loads the count allows
+template <int R>
+__device__ __forceinline__ void load_states(const double* __restrict__ src, double (&e)[R]) {
+    if constexpr (R % 2 == 0) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            const double2 v = *(const double2*)(src + r);
+            e[r] = v.x;
+            e[r + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) e[r] = src[r];
+    }
+}
+
+// A single wave gets an issue slot every 2.5 ns or so, whatever the instruction (vector, scalar, wait:
+// measured), and the recursion is one wave per direction, so a step costs what its instruction
+// count says.  The loops below are written to keep that count down: no bounds test and no address
+// arithmetic per step (the emission table is padded, so a prefetch past either end of a sample
+// reads memory that is never used), no conversion, zero fill by the DPP itself, LDS slots at
+// compile-time offsets, the scaling test two compares every fourth step, the hand-over counters
+// touched once per group of steps, the stores left to other waves.
+template <int R>
+__global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restrict__ emis,
+                                                          const int32_t* __restrict__ labels,
+                                                          const int32_t* __restrict__ label_len,
+                                                          const int32_t* __restrict__ logit_len, int T_, int U,
+                                                          double* __restrict__ alpha, double* __restrict__ beta,
+                                                          double* __restrict__ ll) {
+    static_assert(R % 2 == 0, "a lane holds whole (blank, label) pairs: even r is a blank state, odd r a label");
     constexpr int Sp = 64 * R;
-    constexpr bool kParity = (R % 2) == 0;      // state parity is then a property of r alone
-    // emission rows fetched ahead of the recursion (a step is some 300 cycles, a load under the
-    // row workgroups' traffic a few microseconds).  Measured on gfx950: 12 and 16 steps ahead run
-    // the recursion at its arithmetic pace; 20 and more are twice as slow.
-    constexpr int CTC_PF = R <= 2 ? 16 : 8;
+    constexpr int HR = R / 2;                   // labels per lane = doubles per lane in an emission row
+    constexpr int Lp = Sp / 2;
+    constexpr bool kParity = true;
+    // emission rows fetched ahead of the recursion through a ring of registers; one trip of the
+    // unrolled loop is one turn of that ring
+    constexpr int PF = R <= 4 ? 16 : (R <= 12 ? 8 : 4);
+    static_assert(PF <= CTC_EMIS_PAD, "prefetch runs past the padding");
+    // The state vectors leave through LDS.  A wave that both loads and stores waits for its stores
+    // whenever it waits for a load (one counter serves both), and a store takes a microsecond or
+    // more to be acknowledged, so waves 2 and 3 do the storing: the recursion waves write each
+    // vector into a ring of DS slots and publish a count every G vectors, the flush waves copy
+    // published slots to memory and publish how far they got.  LDS operations of a CU are carried
+    // out in the order they were issued, so a count written after the data is seen after the data.
+    // Vector i (i >= 1) sits in slot (i - 1) % DS, vector 0 in slot DS - 1.
+    constexpr int DS = R <= 2 ? 32 : (R <= 4 ? 16 : (R <= 8 ? 8 : 4));
+    constexpr int G = DS / 2;
+    static_assert(2 * DS * Sp * 8 <= 65536 && (PF % G == 0 || G % PF == 0), "LDS ring");
+    __shared__ double ring_s[2][DS][Sp];
+    __shared__ int prod[2], cons[2];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int dir = threadIdx.x >> 6;
+    const int dir = (threadIdx.x >> 6) & 1;
+    const bool flusher = threadIdx.x >= 128;
     const int L = min(max(label_len[b], 0), U);
     const int Sb = 2 * L + 1;
     int len = logit_len[b];
     if (len > T_) len = T_;
     if (len <= 0) {
-        if (dir == 0 && lane == 0) ll[b] = 0.0;
+        if (threadIdx.x == 0) ll[b] = 0.0;
         return;
     }
-    const T* lb = logits + (long)b * T_ * ldl;
-    // per-state static data: class, validity (as an additive penalty) and the skip transitions
-    int cls[R];
-    float pen[R];
-    bool skip_in[R], skip_out[R];
+    if (threadIdx.x < 2) {
+        prod[threadIdx.x] = 0;
+        cons[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (flusher) {
+        // vector number i of a direction belongs to time i (alpha) or len-1-i (beta)
+        double* dst = (dir == 0 ? alpha : beta) + (long)b * T_ * Sp + lane * R;
+        int done = 0;
+        while (done < len) {
+            int avail;
+            while ((avail = lds_peek(&prod[dir])) <= done) __builtin_amdgcn_s_sleep(2);
+            // published vectors come in groups of G (the last group may be short): all LDS reads of
+            // a group are issued before the first store waits for them
+            for (; done + G <= avail; done += G) {
+                double v[G][R];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double* src = &ring_s[dir][(done + g + DS - 1) % DS][lane * R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v[g][r] = src[r];
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int t = dir == 0 ? done + g : len - 1 - (done + g);
+                    store_states<R>(dst + (long)t * Sp, v[g]);
+                }
+            }
+            for (; done < avail; ++done) {
+                const int t = dir == 0 ? done : len - 1 - done;
+                double v[R];
+                const double* src = &ring_s[dir][(done + DS - 1) % DS][lane * R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = src[r];
+                store_states<R>(dst + (long)t * Sp, v);
+            }
+            lds_poke(&cons[dir], done);
+        }
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    // the skip transitions of each state as factors 0 / 1
+    double skip_in[R], skip_out[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int s = lane * R + r;
-        int c = blank;
         bool si = false, so = false;
         if ((s & 1) && s < Sb) {
             const int u = s >> 1;
-            c = labels[(long)b * U + u];
+            const int c = labels[(long)b * U + u];
             if (u >= 1) si = c != labels[(long)b * U + u - 1];
             if (s + 2 < Sb) so = labels[(long)b * U + u + 1] != c;
         }
-        cls[r] = (c >= 0 && c < V) ? c : blank;
-        pen[r] = s < Sb ? 0.f : CTC_LOGZERO;
-        skip_in[r] = si;
-        skip_out[r] = so;
+        skip_in[r] = si ? 1.0 : 0.0;
+        skip_out[r] = so ? 1.0 : 0.0;
     }
-    // emissions are fetched CTC_PF steps ahead through a ring of registers: a step is far shorter
-    // than the latency of a load, so a one-step prefetch would leave every step waiting for memory
-    T ring[CTC_PF][R];
-    T ringb[CTC_PF];
-    // the blank logit goes through a vector register like the others (a uniform address read as a
-    // scalar would put the whole ring of them into scalar registers, which do not hold that many)
-    int vblank = blank;
-    asm volatile("" : "+v"(vblank));
-    auto fetch = [&](int j, int t) {
-        const T* rowp = lb + (long)t * ldl;
-        ringb[j] = rowp[vblank];
+    double a[R];
+    long cum = 0;
+    // Scaling.  Every fourth step two compares tell whether the largest state of the wave has left
+    // [2^-256, 2^256]; only then is its exponent found (a reduction over the wave) and taken out of
+    // every state.  An emission within 2^(+-130) per step cannot carry a state from that band to the
+    // end of the double range in four steps; one beyond that leaves a zero or non-finite path sum,
+    // and the sample goes to the slow path.
+    auto rescale = [&]() {
+        int mh = __double2hiint(a[0]);
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (!(kParity && (r % 2) == 0)) ring[j][r] = rowp[cls[r]];
-    };
-    auto emis = [&](int j, float (&e)[R]) {
-        const float xb = to_f32<T>(ringb[j]);
+        for (int r = 1; r < R; ++r) mh = max(mh, __double2hiint(a[r]));
+        const bool big = __ballot(mh > ((1023 + 256) << 20)) != 0;
+        const bool small = __ballot(mh >= ((1023 - 256) << 20)) == 0;
+        if (big || small) {
+            const int k = scale_exponent(wave_imax_dpp(mh));
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (kParity && (r % 2) == 0) e[r] = pen[r];      // a blank state: logit - logit[blank] = 0
-            else e[r] = fmaf(to_f32<T>(ring[j][r]) - xb, CTC_LOG2E, pen[r]);
+            for (int r = 0; r < R; ++r) a[r] = ldexp(a[r], -k);
+            cum += k;
         }
     };
-    float a[R];
-    if (dir == 0) {
-        // ---------------- alpha
-        double cum = 0.0;
-        float* ab = alpha + (long)b * T_ * Sp + lane * R;
+    // vector i = 1 + k * PF + j of trip k goes into slot (k * PF + j) % DS: ``base`` is the trip's
+    // part of that, j the compile-time part
+    double* myring = &ring_s[dir][0][lane * R];
+    auto put = [&](int slot, const double (&v)[R]) {
+        double* dstp = myring + slot * Sp;
 #pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) fetch(j, j < len ? j : len - 1);
-        for (int tb = 0; tb < len; tb += CTC_PF) {
+        for (int r = 0; r < R; ++r) dstp[r] = v[r];
+    };
+    // before vector i (i - 1 a multiple of G) is written, the G slots from its own on must be empty
+    auto wait_room = [&](int i) {
+        while (i + G - lds_peek(&cons[dir]) > DS) __builtin_amdgcn_s_sleep(1);
+    };
+    // emission rows are read through a pointer that moves one row per step
+    const double* ep;
+    double ring[PF][HR];
+    auto trips = [&](auto step, int row_stride) {
+        // ring slot j of trip k holds the emissions for vector 1 + k * PF + j
 #pragma unroll
-            for (int j = 0; j < CTC_PF; ++j) {
-                const int t = tb + j;
-                if (t >= len) continue;
-                float e[R];
-                emis(j, e);
-                fetch(j, (t + CTC_PF < len) ? t + CTC_PF : len - 1);
-                if (j == 0 && t == 0) {
+        for (int j = 0; j < PF; ++j) load_states<HR>(ep + (long)j * row_stride, ring[j]);
+        ep += (long)PF * row_stride;
+        int i = 1, base = 0;
+        for (; i + PF <= len; i += PF) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = (lane * R + r < 2) ? e[r] : CTC_LOGZERO;
-                } else {
-                    // neighbours: state s-1 and s-2; across the lane boundary they live in lane-1
-                    const float p1 = lane_prev(a[R - 1], CTC_LOGZERO);
-                    const float p2 = (R >= 2) ? lane_prev(a[R >= 2 ? R - 2 : 0], CTC_LOGZERO)
-                                              : lane_prev(p1, CTC_LOGZERO);
-                    float na[R];
+            for (int j = 0; j < PF; ++j) {
+                double p[HR];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float x1 = r >= 1 ? a[r >= 1 ? r - 1 : 0] : p1;
-                        float v;
-                        if (kParity && (r % 2) == 0) {
-                            v = lse2_2(a[r], x1);
-                        } else {
-                            float x2 = r >= 2 ? a[r >= 2 ? r - 2 : 0] : (r == 1 ? p1 : p2);
-                            if (!skip_in[r]) x2 = CTC_LOGZERO;
-                            v = lse3_2(a[r], x1, x2);
-                        }
-                        na[r] = v + e[r];
-                    }
+                for (int r = 0; r < HR; ++r) p[r] = ring[j][r];
+                load_states<HR>(ep + (long)j * row_stride, ring[j]);
+                if (j % G == 0) wait_room(i + j);
+                step(p, (1 + j) & 3);
+                put(DS >= PF ? base + j : j % DS, a);
+                if (j % G == G - 1) lds_poke(&prod[dir], i + j + 1);
+            }
+            ep += (long)PF * row_stride;
+            base = (base + PF) & (DS - 1);
+        }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = na[r];
-                }
-                if ((j & 3) == 0) {
-                    // the values are logarithms: shifting them by the maximum only keeps them small
-                    // for the sake of fp32 resolution, so every fourth step is enough
-                    float mx = a[0];
-#pragma unroll
-                    for (int r = 1; r < R; ++r) mx = fmaxf(mx, a[r]);
-                    mx = wave_max_dpp(mx);
-                    cum += (double)mx;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) a[r] = fmaxf(a[r] - mx, CTC_LOGZERO);
-                }
-                store_states<R>(ab + (long)t * Sp, a);
+        for (int j = 0; j < PF; ++j) {
+            if (i + j < len) {
+                if (j % G == 0) wait_room(i + j);
+                step(ring[j], (1 + j) & 3);
+                put(DS >= PF ? base + j : j % DS, a);
+                if (j % G == G - 1) lds_poke(&prod[dir], i + j + 1);
             }
         }
+        lds_poke(&prod[dir], len);
+    };
+    const double* eb = emis + (long)b * T_ * Lp + lane * HR;
+    if (dir == 0) {
+        // ---------------- alpha: vector i is time i; step i reads the emissions of time i
+        auto step = [&](const double (&p)[HR], int ph) {
+            // neighbours: state s-1 and s-2; across the lane boundary they live in lane-1.  The
+            // even r are blank states: factor 1, or a state beyond the sample's last one, which
+            // only zeros ever reach
+            const double p1 = lane_prev_f64(a[R - 1]);
+            const double p2 = 0.0;
+            double na[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double x1 = r >= 1 ? a[r >= 1 ? r - 1 : 0] : p1;
+                if (kParity && (r % 2) == 0) {
+                    na[r] = a[r] + x1;
+                } else {
+                    const double x2 = r >= 2 ? a[r >= 2 ? r - 2 : 0] : (r == 1 ? p1 : p2);
+                    na[r] = fma(x2, skip_in[r], a[r] + x1) * p[r >> 1];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = na[r];
+            if (ph == 0) rescale();
+        };
+        {
+            double p0[HR];
+            load_states<HR>(eb, p0);
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = 0.0;
+            if (lane == 0) {
+                a[0] = 1.0;
+                a[1] = p0[0];
+            }
+            put(DS - 1, a);
+            if (len == 1) lds_poke(&prod[dir], 1);
+        }
+        ep = eb + Lp;
+        trips(step, Lp);
         // path sum from the two final states at t = len-1
-        float fin = CTC_LOGZERO;
+        double fin = 0.0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int s = lane * R + r;
-            if (s == Sb - 1 || (s == Sb - 2 && Sb >= 2)) fin = (fin == CTC_LOGZERO) ? a[r] : lse2_2(fin, a[r]);
+            if (s == Sb - 1 || (s == Sb - 2 && Sb >= 2)) fin += a[r];
         }
-        const bool live = fin > 0.5f * CTC_LOGZERO;
-        const float fm = wave_max(live ? fin : CTC_LOGZERO);
-        const float fs = wave_sum(live ? __builtin_amdgcn_exp2f(fin - fm) : 0.f);
-        if (lane == 0) ll[b] = fs > 0.f ? cum + (double)fm + (double)__builtin_amdgcn_logf(fs) : -(double)INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fin += __shfl_xor(fin, o, 64);
+        if (lane == 0) ll[b] = (fin > 0.0 && fin < (double)INFINITY) ? (double)cum + log2(fin) : -(double)INFINITY;
     } else {
-        // ---------------- beta: beta[len-1][s] = 0 for final states; beta[t][s] = lse over successors
-        // s' in {s, s+1, s+2(skip)} of beta[t+1][s'] + e[t+1][s']
-        float* bb = beta + (long)b * T_ * Sp + lane * R;
+        // ---------------- beta: vector i is time len-1-i.  beta[len-1][s] = 1 for final states;
+        // beta[t][s] = sum over successors s' in {s, s+1, s+2(skip)} of beta[t+1][s'] * p[t+1][s'],
+        // so step i reads the emissions of time len-i
+        auto step = [&](const double (&p)[HR], int ph) {
+            double w[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) w[r] = (r % 2) == 0 ? a[r] : a[r] * p[r >> 1];
+            const double n1 = lane_next_f64(w[0]);
+            const double n2 = (R >= 2) ? lane_next_f64(w[R >= 2 ? 1 : 0]) : lane_next_f64(n1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double x1 = (r + 1 < R) ? w[r + 1 < R ? r + 1 : 0] : n1;
+                if (kParity && (r % 2) == 0) {
+                    a[r] = w[r] + x1;
+                } else {
+                    const double x2 = (r + 2 < R) ? w[r + 2 < R ? r + 2 : 0] : (r + 2 == R ? n1 : n2);
+                    a[r] = fma(x2, skip_out[r], w[r] + x1);
+                }
+            }
+            if (ph == 0) rescale();
+        };
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int s = lane * R + r;
             const bool fin = (s == Sb - 1) || (s == Sb - 2 && Sb >= 2);
-            a[r] = fin ? 0.f : CTC_LOGZERO;
+            a[r] = fin ? 1.0 : 0.0;
         }
-        store_states<R>(bb + (long)(len - 1) * Sp, a);
-        // step t (going down from len-2) consumes the emissions of t+1; ring slot j of a trip holds
-        // the emissions of time t+1 for t = top - j
-#pragma unroll
-        for (int j = 0; j < CTC_PF; ++j) fetch(j, (len - 1 - j) >= 0 ? len - 1 - j : 0);
-        for (int top = len - 2; top >= 0; top -= CTC_PF) {
-#pragma unroll
-            for (int j = 0; j < CTC_PF; ++j) {
-                const int t = top - j;
-                if (t < 0) continue;
-                float e[R];
-                emis(j, e);
-                fetch(j, (t + 1 - CTC_PF) >= 0 ? t + 1 - CTC_PF : 0);
-                // w[s] = beta[t+1][s] + e[t+1][s]
-                float w[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) w[r] = a[r] + e[r];
-                const float n1 = lane_next(w[0], CTC_LOGZERO);
-                const float n2 = (R >= 2) ? lane_next(w[R >= 2 ? 1 : 0], CTC_LOGZERO) : lane_next(n1, CTC_LOGZERO);
-                float nb[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float x1 = (r + 1 < R) ? w[r + 1 < R ? r + 1 : 0] : n1;
-                    if (kParity && (r % 2) == 0) {
-                        nb[r] = lse2_2(w[r], x1);
-                    } else {
-                        float x2 = (r + 2 < R) ? w[r + 2 < R ? r + 2 : 0] : (r + 2 == R ? n1 : n2);
-                        if (!skip_out[r]) x2 = CTC_LOGZERO;
-                        nb[r] = lse3_2(w[r], x1, x2);
-                    }
-                }
-                if ((j & 3) == 0) {
-                    float mx = nb[0];
-#pragma unroll
-                    for (int r = 1; r < R; ++r) mx = fmaxf(mx, nb[r]);
-                    mx = wave_max_dpp(mx);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) nb[r] = fmaxf(nb[r] - mx, CTC_LOGZERO);
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) a[r] = nb[r];
-                store_states<R>(bb + (long)t * Sp, a);
-            }
-        }
+        put(DS - 1, a);
+        if (len == 1) lds_poke(&prod[dir], 1);
+        ep = eb + (long)(len - 1) * Lp;
+        trips(step, -Lp);
     }
 }
 
@@ -511,56 +761,48 @@ __device__ __forceinline__ double lse_pair(double a, double b) {
     return m + log(exp(a - m) + exp(b - m));
 }
 
-// loss[b] = -(ln of the blank-relative path sum - sum over t of (lse - logit[blank])); one workgroup
-// per sample, of which one wave does this sum.
-//
-// A sample whose labels do not fit its frames (path sum zero) takes the slow path instead, on all
-// four waves: tf.nn.ctc_loss's dense recursion restated literally for that sample (reference call
-// site athena/loss.py:38-45) -- every one of the U label states and U+1 blank states of the padded
-// label row plus the silent start state, the leaky initial and final vectors, the loss read from the
-// backward recursion -- in double precision, states in LDS.  It overwrites the sample's alpha / beta
-// rows with that lattice (same state order: even = blank, odd = label; log2 units; shifted by the
-// row maximum) and raises flags[b], which tells ctc_grad to walk all 2U+1 states.
-template <typename T>
-__global__ __launch_bounds__(256) void ctc_finish_kernel(const T* __restrict__ logits, int ldl,
-                                                         const int32_t* __restrict__ labels,
-                                                         const int32_t* __restrict__ label_len,
-                                                         const int32_t* __restrict__ logit_len, int T_, int V,
-                                                         int U, int blank, int Sp, const float* __restrict__ lse,
-                                                         const float* __restrict__ nrm, float* __restrict__ alpha,
-                                                         float* __restrict__ beta, const double* __restrict__ ll,
-                                                         int32_t* __restrict__ flags, float* __restrict__ loss) {
-    __shared__ double st[2][64 * CTC_MAX_R];
-    __shared__ float red[32];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// The slow path of the third launch, one workgroup per sample, which leaves at once unless the lattice
+// found no path for its sample (path sum zero: the labels do not fit the frames, or an emission fell
+// outside what the probability-domain recursion holds).  For such a sample: tf.nn.ctc_loss's dense
+// recursion restated literally (reference call site athena/loss.py:38-45) -- every one of the U label
+// states and U+1 blank states of the padded label row plus the silent start state, the leaky initial
+// and final vectors, the loss read from the backward recursion -- in double precision on logarithms,
+// states in LDS.  It keeps its forward lattice (log2 units, shifted by the row maximum) in the
+// sample's part of the alpha buffer, writes the posterior list of all U labels (and, with ``grad``,
+// the gradient columns that have an occupancy) from the backward loop and raises flags[b], which
+// tells ctc_grad to scatter all U + 1 entries.
+struct CtcSlowLds {
+    double st[2][64 * CTC_MAX_R];
+    float red[32];
+    float tot[1][CTC_MAX_U];          // occupancy by label position
+    int16_t first[CTC_MAX_U];         // first position with the same class (-1: the blank class)
+};
+template <typename T, typename TG>
+__device__ __forceinline__ void ctc_slow_path(CtcSlowLds& lds, int b, const T* __restrict__ logits, int ldl,
+                                              const int32_t* __restrict__ labels,
+                                              const int32_t* __restrict__ label_len,
+                                              const int32_t* __restrict__ logit_len, int T_, int V, int U,
+                                              int blank, int Sp, int Up, const float* __restrict__ lse,
+                                              double* __restrict__ alpha, float* __restrict__ occ,
+                                              const int32_t* __restrict__ first_g,
+                                              const double* __restrict__ ll, int32_t* __restrict__ flags,
+                                              float* __restrict__ loss, float gscale, TG* __restrict__ grad) {
+    double (&st)[2][64 * CTC_MAX_R] = lds.st;
+    float (&red)[32] = lds.red;
+    float (&tot)[1][CTC_MAX_U] = lds.tot;
+    int16_t (&first)[CTC_MAX_U] = lds.first;
+    const int tid = threadIdx.x;
     int len = logit_len[b];
     if (len > T_) len = T_;
+    if (len <= 0 || ll[b] != -(double)INFINITY) return;
     const int L = min(max(label_len[b], 0), U);
-    if (len <= 0) {
-        // no frames: TensorFlow reads the loss off its final vector at the start state
-        if (tid == 0) {
-            loss[b] = L == 0 ? 0.f : (float)(-CTC_TF_LOG0);
-            flags[b] = 0;
-        }
-        return;
+    const int32_t* lab = labels + (long)b * U;
+    if (grad) {
+        for (int u = tid; u < U; u += 256) first[u] = (int16_t)first_g[(long)b * U + u];
+        __syncthreads();
     }
-    const double llb = ll[b];
-    if (llb != -(double)INFINITY) {
-        if (tid >= 64) return;
-        double acc = 0.0;
-        for (int t = lane; t < len; t += 64) acc += (double)nrm[(long)b * T_ + t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) {
-            loss[b] = (float)(acc - llb * CTC_LN2);
-            flags[b] = 0;
-        }
-        return;
-    }
-    // ---------------- slow path
     const int S2 = 2 * U + 1;
     const T* lb = logits + (long)b * T_ * ldl;
-    const int32_t* lab = labels + (long)b * U;
     constexpr int PER = (64 * CTC_MAX_R) / 256;
     int cls[PER];
     bool skip_in[PER], skip_out[PER];
@@ -582,8 +824,7 @@ __global__ __launch_bounds__(256) void ctc_finish_kernel(const T* __restrict__ l
     auto emission = [&](int t, int i) -> double {
         return (double)to_f32<T>(lb[(long)t * ldl + cls[i]]) - (double)lse[(long)b * T_ + t];
     };
-    float* ab = alpha + (long)b * T_ * Sp;
-    float* bb = beta + (long)b * T_ * Sp;
+    float* ab = (float*)(alpha + (long)b * T_ * Sp);     // forward lattice in floats, row pitch Sp
     // forward: fwd[t+1][s] = lse over predecessors of fwd[t] + emission at t
     double start = 0.0;
 #pragma unroll
@@ -632,11 +873,64 @@ __global__ __launch_bounds__(256) void ctc_finish_kernel(const T* __restrict__ l
     cur = 0;
     __syncthreads();
     for (int t = len - 1; t >= 0; --t) {
-        // beta[t] = bwd[t+1]
+        // beta[t] = bwd[t+1]: the posterior of row t is alpha[t] * beta[t], normalised
+        {
+            float pv[PER];
+            float pm = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int s = tid + 256 * i;
-            if (s < S2) bb[(long)t * Sp + s] = fmaxf((float)(st[cur][s] * (double)CTC_LOG2E), CTC_LOGZERO);
+            for (int i = 0; i < PER; ++i) {
+                const int s = tid + 256 * i;
+                pv[i] = -INFINITY;
+                if (s < S2) {
+                    pv[i] = ab[(long)t * Sp + s] + fmaxf((float)(st[cur][s] * (double)CTC_LOG2E), CTC_LOGZERO);
+                    pm = fmaxf(pm, pv[i]);
+                }
+            }
+            pm = block_max(pm, red);
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                pv[i] = (tid + 256 * i < S2) ? __builtin_amdgcn_exp2f(pv[i] - pm) : 0.f;
+                ps += pv[i];
+            }
+            ps = block_sum(ps, red);
+            const float inv = ps > 0.f ? 1.f / ps : 0.f;
+            float* orow = occ + ((long)b * T_ + t) * Up;
+            if (grad) {
+                for (int u = tid; u < U; u += 256) tot[0][u] = 0.f;
+                __syncthreads();
+            }
+            float bl = 0.f;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int s = tid + 256 * i;
+                if (s < S2) {
+                    if (s & 1) {
+                        orow[1 + (s >> 1)] = pv[i] * inv;
+                        if (grad) {
+                            const int fu = first[s >> 1];
+                            if (fu < 0) bl += pv[i] * inv;
+                            else atomicAdd(&tot[0][fu], pv[i] * inv);
+                        }
+                    } else {
+                        bl += pv[i] * inv;
+                    }
+                }
+            }
+            bl = block_sum(bl, red);
+            if (tid == 0) orow[0] = bl;
+            if (grad) {
+                const T* lr = lb + (long)t * ldl;
+                TG* gr = grad + ((long)b * T_ + t) * ldl;
+                const float l = lse[(long)b * T_ + t];
+                for (int u = tid; u < U; u += 256) {
+                    const int c = lab[u];
+                    if (first[u] == u && c >= 0 && c < V)
+                        ctc_store1<TG>(gr + c, gscale * (__expf(to_f32<T>(lr[c]) - l) - tot[0][u]));
+                }
+                if (tid == 0) ctc_store1<TG>(gr + blank, gscale * (__expf(to_f32<T>(lr[blank]) - l) - bl));
+                __syncthreads();
+            }
         }
         // w[s] = bwd[t+1][s] + emission at t, parked in the other buffer
 #pragma unroll
@@ -678,58 +972,180 @@ __global__ __launch_bounds__(256) void ctc_finish_kernel(const T* __restrict__ l
     }
 }
 
-// ---------------------------------------------------------------- ctc_grad
-// One workgroup per logits row at a time.  The row is fetched into registers first; while it is in
-// flight every wave works out the normaliser of the state posterior alpha+beta for itself (no
-// workgroup barrier), the states are scattered by class into an LDS accumulator, and then
-// grad = scale * (softmax - occupancy) is streamed out, each thread clearing the accumulator
-// entries it consumed.
-#define CTC_OCC_CHUNK 8192
-#define CTC_GRAD_VEC 8          // 4-wide column groups per thread and chunk: 256 * 8 * 4 = CTC_OCC_CHUNK
-template <typename TL>
-struct CtcRowVec;
-template <>
-struct CtcRowVec<float> {
-    float4 v;
-    __device__ __forceinline__ void load(const float* p) { v = *(const float4*)p; }
-    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-};
-template <>
-struct CtcRowVec<bf16_t> {
-    uint2 v;
-    __device__ __forceinline__ void load(const bf16_t* p) { v = *(const uint2*)p; }
-    __device__ __forceinline__ float get(int i) const {
-        const uint32_t w = i < 2 ? v.x : v.y;
-        return __uint_as_float((i & 1) ? (w & 0xffff0000u) : (w << 16));
+// Third CTC launch.  CTC_POST_ROWS logits rows of one sample per workgroup, one wave per row at a
+// time: the posterior over the lattice states of the row, alpha * beta normalised (the power-of-two
+// scales of the two factors are constants of the row and cancel), leaves as a short list --
+// occ[row][0] = all blank states together, occ[row][1 + u] = the state of label u -- so that
+// ctc_grad neither reads the lattices nor reduces anything.  Wave 0 of a sample's first workgroup
+// also writes loss[b] = -(ln of the blank-relative path sum - sum over t of (lse - logit[blank])).
+//
+// With ``grad`` the wave also writes the gradient columns of its row that have an occupancy.  The
+// last B workgroups of the launch are the slow path, one per sample.
+#define CTC_POST_ROWS 4
+template <typename T, typename TG, int R>
+__global__ __launch_bounds__(256) void ctc_post_kernel(const T* __restrict__ logits,
+                                                       const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ label_len,
+                                                       const int32_t* __restrict__ logit_len, int B, int T_,
+                                                       int V, int U, int blank, int ldl, int Up, int chunks,
+                                                       const float* __restrict__ lse,
+                                                       const float* __restrict__ nrm,
+                                                       const double* __restrict__ emis,
+                                                       double* __restrict__ alpha,
+                                                       const double* __restrict__ beta, float* __restrict__ occ,
+                                                       const int32_t* __restrict__ first_g,
+                                                       const double* __restrict__ ll,
+                                                       int32_t* __restrict__ flags, float* __restrict__ loss,
+                                                       float gscale, TG* __restrict__ grad) {
+    constexpr int Sp = 64 * R, Lp = Sp / 2;
+    __shared__ CtcSlowLds slow_lds;
+    __shared__ float tot[CTC_POST_ROWS][Lp];     // occupancy by label position, one set per wave
+    if ((int)blockIdx.x >= B * chunks) {
+        // the last B workgroups: one per sample, for the samples the lattice found no path for
+        ctc_slow_path<T, TG>(slow_lds, blockIdx.x - B * chunks, logits, ldl, labels, label_len, logit_len, T_, V, U,
+                             blank, Sp, Up, lse, alpha, occ, first_g, ll, flags, loss, gscale, grad);
+        return;
     }
-};
-template <typename TG>
-__device__ __forceinline__ void ctc_store4(TG* p, float a, float b, float c, float d);
-template <>
-__device__ __forceinline__ void ctc_store4<float>(float* p, float a, float b, float c, float d) {
-    *(float4*)p = make_float4(a, b, c, d);
-}
-template <>
-__device__ __forceinline__ void ctc_store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
-    union { bf16_t h[4]; uint2 u; } pk;
-    pk.h[0] = (bf16_t)a; pk.h[1] = (bf16_t)b; pk.h[2] = (bf16_t)c; pk.h[3] = (bf16_t)d;
-    *(uint2*)p = pk.u;
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = chunk * CTC_POST_ROWS + wv;
+    const long row = (long)b * T_ + min(t, T_ - 1);
+    // Everything the row needs is requested at once, before anything is tested (a load that waited
+    // for the lengths, and the lengths for each other, would cost a memory latency each): lane l
+    // holds the states l, l + 64, ...; a state and its lane have the same parity: even lanes hold
+    // blank states, odd lanes labels.  States beyond the sample's last one hold zeros.
+    int len = logit_len[b];
+    const int Lraw = label_len[b];
+    const double llb = ll[b];
+    const double* ar = alpha + row * Sp;
+    const double* br = beta + row * Sp;
+    double av[R], bv[R], pe[R];
+    int cl[R], fu[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        av[i] = ar[lane + 64 * i];
+        bv[i] = br[lane + 64 * i];
+    }
+    if (grad != nullptr && U > 0) {
+        const int32_t* lab = labels + (long)b * U;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int u = (lane + 64 * i) >> 1;
+            cl[i] = lab[min(u, U - 1)];
+            fu[i] = first_g[(long)b * U + min(u, U - 1)];
+            pe[i] = emis[row * Lp + u];
+        }
+    }
+    const float nr = grad ? nrm[row] : 0.f;
+    if (len > T_) len = T_;
+    const int L = min(max(Lraw, 0), U);
+    if (len <= 0) {
+        // no frames: TensorFlow reads the loss off its final vector at the start state
+        if (chunk == 0 && tid == 0) {
+            loss[b] = L == 0 ? 0.f : (float)(-CTC_TF_LOG0);
+            flags[b] = 0;
+        }
+        return;
+    }
+    if (llb == -(double)INFINITY) return;        // the slow path's sample
+    if (chunk == 0 && wv == 0) {
+        double acc = 0.0;
+        for (int tt = lane; tt < len; tt += 64) acc += (double)nrm[(long)b * T_ + tt];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) {
+            loss[b] = (float)(acc - llb * CTC_LN2);
+            flags[b] = 0;
+        }
+    }
+    if (t >= len) return;
+    const int Sb = 2 * L + 1;
+    const bool fix = grad != nullptr && L > 0;   // (wave-uniform)
+    int mh = 0;
+    double w[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        w[i] = lane + 64 * i < Sb ? av[i] * bv[i] : 0.0;
+        mh = max(mh, __double2hiint(w[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mh = max(mh, __shfl_xor(mh, o, 64));
+    const int k = scale_exponent(mh);
+    float f[R];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        f[i] = (float)ldexp(w[i], -k);
+        sm += f[i];
+    }
+    sm = wave_sum(sm);
+    const float inv = sm > 0.f ? 1.f / sm : 0.f;
+    float* orow = occ + row * Up;
+    float bl = 0.f;
+    if (fix) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int s = lane + 64 * i;
+            if ((s & 1) && s < Sb) tot[wv][s >> 1] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int s = lane + 64 * i;
+        f[i] *= inv;
+        if (s < Sb) {
+            if (s & 1) {
+                orow[1 + (s >> 1)] = f[i];
+                if (fix) {
+                    if (fu[i] < 0) bl += f[i];
+                    else atomicAdd(&tot[wv][fu[i]], f[i]);
+                }
+            } else {
+                bl += f[i];
+            }
+        }
+    }
+    bl = wave_sum(bl);
+    if (lane == 0) orow[0] = bl;
+    if (grad) {
+        // The row launch left gscale * softmax in the row: the columns with an occupancy are written
+        // again, complete.  softmax of a label's column = its emission (relative to blank) times the
+        // softmax of the blank column, exp(-(lse - logit[blank])).
+        __threadfence_block();
+        TG* gr = grad + row * ldl;
+        const double pb = (double)__expf(-nr);
+        if (fix) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int s = lane + 64 * i;
+                if ((s & 1) && s < Sb && fu[i] == (s >> 1) && cl[i] >= 0 && cl[i] < V)
+                    ctc_store1<TG>(gr + cl[i], gscale * ((float)(pe[i] * pb) - tot[wv][s >> 1]));
+            }
+        }
+        if (lane == 0) ctc_store1<TG>(gr + blank, gscale * ((float)pb - bl));
+    }
 }
 
+// ---------------------------------------------------------------- ctc_grad
+// One workgroup per logits row at a time.  The row's posterior list (at most U + 1 entries) and then
+// the row itself are requested; the list is scattered by class into an LDS accumulator (labels that
+// repeat add up there), and grad = scale * (softmax - occupancy) is streamed out, each thread
+// clearing the accumulator entries it consumed.
+#define CTC_OCC_CHUNK 8192
+#define CTC_GRAD_VEC 8          // 4-wide column groups per thread and chunk: 256 * 8 * 4 = CTC_OCC_CHUNK
+#define CTC_LIST_PER ((64 * CTC_MAX_R / 2 + 255) / 256)      // list entries per thread: U + 1 <= 512
 template <typename TL, typename TG>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const TL* __restrict__ logits, int ldl,
                                                        const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
                                                        const int32_t* __restrict__ logit_len, int T_, int V, int U,
-                                                       int blank, int Sp, const float* __restrict__ lse,
-                                                       const float* __restrict__ alpha,
-                                                       const float* __restrict__ beta,
+                                                       int blank, int Up, const float* __restrict__ lse,
+                                                       const float* __restrict__ occ,
                                                        const int32_t* __restrict__ flags,
                                                        const float* __restrict__ grad_scale, float host_scale,
                                                        TG* __restrict__ grad, int rows_total, int chunk) {
-    extern __shared__ float occ[];       // [chunk]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < chunk; c += blockDim.x) occ[c] = 0.f;
+    extern __shared__ float acc[];       // [chunk]
+    for (int c = threadIdx.x; c < chunk; c += blockDim.x) acc[c] = 0.f;
     __syncthreads();
     const float scale = host_scale * (grad_scale ? grad_scale[0] : 1.f);
     // columns [0, ldl) are written: logits columns get the gradient, the padding zeros.  ldl % 4 == 0.
@@ -741,40 +1157,43 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const TL* __restrict__ lo
             continue;
         }
         // a sample without a fitting alignment carries TensorFlow's lattice over the whole padded label row
-        const int Sb = flags[b] ? 2 * U + 1 : 2 * min(max(label_len[b], 0), U) + 1;
-        const float* ar = alpha + (long)row * Sp;
-        const float* br = beta + (long)row * Sp;
+        const int nst = flags[b] ? U : min(max(label_len[b], 0), U);
+        const float* orow = occ + (long)row * Up;
+        const int32_t* lab = labels + (long)b * U;
         const TL* lr = logits + (long)row * ldl;
         const float l = lse[row];
         for (int v0 = 0; v0 < ldl; v0 += chunk) {
-            // the row (this chunk of it) into registers
+            // the list first (loads come back in the order they were asked for), then the row
+            // (this chunk of it) into registers
+            int cj[CTC_LIST_PER];
+            float oj[CTC_LIST_PER];
+#pragma unroll
+            for (int q = 0; q < CTC_LIST_PER; ++q) {
+                const int j = threadIdx.x + 256 * q;
+                cj[q] = -1;
+                oj[q] = 0.f;
+                if (j <= nst) {
+                    cj[q] = j == 0 ? blank : lab[j - 1];
+                    oj[q] = orow[j];
+                }
+            }
             CtcRowVec<TL> x[CTC_GRAD_VEC];
 #pragma unroll
             for (int i = 0; i < CTC_GRAD_VEC; ++i) {
                 const int c = v0 + (i * 256 + threadIdx.x) * 4;
                 if (i * 1024 < chunk && c < ldl) x[i].load(lr + c);
             }
-            // posterior over the lattice states of this row: every wave normalises for itself
-            float mx = -INFINITY;
-            for (int s = lane; s < Sb; s += 64) mx = fmaxf(mx, ar[s] + br[s]);
-            mx = wave_max(mx);
-            float sm = 0.f;
-            for (int s = lane; s < Sb; s += 64) sm += __builtin_amdgcn_exp2f(ar[s] + br[s] - mx);
-            sm = wave_sum(sm);
-            const float inv = 1.f / sm;
-            for (int s = threadIdx.x; s < Sb; s += 256) {
-                const int cls = (s & 1) ? labels[(long)b * U + (s >> 1)] : blank;
-                if (cls >= v0 && cls < v0 + chunk && cls < V)
-                    atomicAdd(&occ[cls - v0], __builtin_amdgcn_exp2f(ar[s] + br[s] - mx) * inv);
-            }
+#pragma unroll
+            for (int q = 0; q < CTC_LIST_PER; ++q)
+                if (cj[q] >= v0 && cj[q] < v0 + chunk && cj[q] < V) atomicAdd(&acc[cj[q] - v0], oj[q]);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < CTC_GRAD_VEC; ++i) {
                 const int cl = (i * 256 + threadIdx.x) * 4;     // column within the chunk
                 const int c = v0 + cl;
                 if (i * 1024 < chunk && c < ldl) {
-                    const float4 o = *(const float4*)(occ + cl);
-                    if (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) *(float4*)(occ + cl) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 o = *(const float4*)(acc + cl);
+                    if (o.x != 0.f || o.y != 0.f || o.z != 0.f || o.w != 0.f) *(float4*)(acc + cl) = make_float4(0.f, 0.f, 0.f, 0.f);
                     float g[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -801,30 +1220,51 @@ static int ctc_check(const char* name, const void* logits, int dtype, int ldl, i
     return ATHENA_OK;
 }
 
-template <typename T, int R>
-static void launch_ctc_fwd(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
-                           const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
-                           int32_t* argmax, hipStream_t s) {
-    hipLaunchKernelGGL((ctc_fwd_kernel<T, R>), dim3(B + B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len,
-                       logit_len, B, Tn, V, U, blank, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll, argmax);
+static void launch_ctc_lattice(int R, const int32_t* labels, const int32_t* label_len, const int32_t* logit_len, int B,
+                               int Tn, int U, const CtcWorkspace& ws, hipStream_t s) {
+#define CTC_LAT(N)                                                                                              \
+    hipLaunchKernelGGL((ctc_lattice_kernel<N>), dim3(B), dim3(256), 0, s, ws.emis, labels, label_len, logit_len, \
+                       Tn, U, ws.alpha, ws.beta, ws.ll)
+    switch (R) {
+        case 2: CTC_LAT(2); break;
+        case 4: CTC_LAT(4); break;
+        case 6: CTC_LAT(6); break;
+        case 8: CTC_LAT(8); break;
+        case 12: CTC_LAT(12); break;
+        default: CTC_LAT(CTC_MAX_R); break;
+    }
+#undef CTC_LAT
 }
 
-template <typename T>
-static void dispatch_ctc_fwd(int R, const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
-                             const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
-                             int32_t* argmax, hipStream_t s) {
-#define CTC_FWD(N) launch_ctc_fwd<T, N>(logits, ldl, labels, label_len, logit_len, B, Tn, V, U, blank, ws, argmax, s)
-    switch (R) {
-        case 1: CTC_FWD(1); break;
-        case 2: CTC_FWD(2); break;
-        case 3: CTC_FWD(3); break;
-        case 4: CTC_FWD(4); break;
-        case 5: CTC_FWD(5); break;
-        case 7: CTC_FWD(7); break;
-        case 10: CTC_FWD(10); break;
-        default: CTC_FWD(CTC_MAX_R); break;
+// the three launches of the forward pass; with ``grad`` they also leave the gradient
+// gscale * (softmax - occupancy) (rows beyond logit_length and padding columns zero)
+template <typename T, typename TG>
+static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
+                               const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
+                               float* loss, int32_t* argmax, float gscale, TG* grad, hipStream_t s) {
+    if (grad)
+        hipLaunchKernelGGL((ctc_row_kernel<T, TG, true>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels,
+                           label_len, logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first,
+                           gscale, grad);
+    else
+        hipLaunchKernelGGL((ctc_row_kernel<T, TG, false>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels,
+                           label_len, logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first,
+                           gscale, grad);
+    launch_ctc_lattice(ctc_launch_r(2 * U + 1), labels, label_len, logit_len, B, Tn, U, ws, s);
+    const int chunks = (Tn + CTC_POST_ROWS - 1) / CTC_POST_ROWS;
+#define CTC_POST(N)                                                                                             \
+    hipLaunchKernelGGL((ctc_post_kernel<T, TG, N>), dim3(B * chunks + B), dim3(256), 0, s, logits, labels,      \
+                       label_len, logit_len, B, Tn, V, U, blank, ldl, ws.Up, chunks, ws.lse, ws.nrm, ws.emis,   \
+                       ws.alpha, ws.beta, ws.occ, ws.first, ws.ll, ws.flags, loss, gscale, grad)
+    switch (ctc_launch_r(2 * U + 1)) {
+        case 2: CTC_POST(2); break;
+        case 4: CTC_POST(4); break;
+        case 6: CTC_POST(6); break;
+        case 8: CTC_POST(8); break;
+        case 12: CTC_POST(12); break;
+        default: CTC_POST(CTC_MAX_R); break;
     }
-#undef CTC_FWD
+#undef CTC_POST
 }
 
 extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
@@ -837,20 +1277,72 @@ extern "C" int athena_ctc_loss_fwd(const void* logits, int logits_dtype, int ldl
     CtcWorkspace ws;
     ctc_ws_layout(B, T, U, workspace, &ws);
     hipStream_t s = (hipStream_t)stream;
-    const int R = ctc_launch_r(2 * U + 1);
     if (logits_dtype == ATHENA_BF16)
-        dispatch_ctc_fwd<bf16_t>(R, (const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
+        launch_ctc_forward<bf16_t, float>((const bf16_t*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws,
+                                          loss, argmax, 0.f, nullptr, s);
     else
-        dispatch_ctc_fwd<float>(R, (const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, argmax, s);
-    if (logits_dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(ctc_finish_kernel<bf16_t>, dim3(B), dim3(256), 0, s, (const bf16_t*)logits, ldl, labels,
-                           label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll,
-                           ws.flags, loss);
-    else
-        hipLaunchKernelGGL(ctc_finish_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, ldl, labels,
-                           label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.alpha, ws.beta, ws.ll,
-                           ws.flags, loss);
+        launch_ctc_forward<float, float>((const float*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws,
+                                         loss, argmax, 0.f, nullptr, s);
     ATHENA_CHECK_LAUNCH("athena_ctc_loss_fwd");
+    return ATHENA_OK;
+}
+
+extern "C" int athena_ctc_loss_fwd_bwd(const void* logits, int logits_dtype, int ldl, const int32_t* labels,
+                                       const int32_t* label_len, const int32_t* logit_len, int B, int T, int V, int U,
+                                       int blank, float* loss, int32_t* argmax, float grad_scale, void* grad,
+                                       int grad_dtype, void* workspace, size_t workspace_bytes,
+                                       athena_stream_t stream) {
+    int rc = ctc_check("athena_ctc_loss_fwd_bwd", logits, logits_dtype, ldl, B, T, V, U, blank, workspace, workspace_bytes);
+    if (rc) return rc;
+    ATHENA_REQUIRE(labels && label_len && logit_len && loss && grad, ATHENA_E_SHAPE, "athena_ctc_loss_fwd_bwd: null operand");
+    ATHENA_REQUIRE(grad_dtype == ATHENA_F32 || grad_dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "athena_ctc_loss_fwd_bwd: grad dtype");
+    ATHENA_REQUIRE(athena_aligned16(grad), ATHENA_E_ALIGN, "athena_ctc_loss_fwd_bwd: grad must be 16-byte aligned");
+    CtcWorkspace ws;
+    ctc_ws_layout(B, T, U, workspace, &ws);
+    hipStream_t s = (hipStream_t)stream;
+#define CTC_FB(TL, TG)                                                                                            \
+    launch_ctc_forward<TL, TG>((const TL*)logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, ws, loss, \
+                               argmax, grad_scale, (TG*)grad, s)
+    if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CTC_FB(float, float);
+    else if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_BF16) CTC_FB(float, bf16_t);
+    else if (logits_dtype == ATHENA_BF16 && grad_dtype == ATHENA_BF16) CTC_FB(bf16_t, bf16_t);
+    else CTC_FB(bf16_t, float);
+#undef CTC_FB
+    ATHENA_CHECK_LAUNCH("athena_ctc_loss_fwd_bwd");
+    return ATHENA_OK;
+}
+
+// x *= upstream[0] / expected unless the two are equal: every workgroup reads the two scalars and
+// leaves at once in the expected case
+template <typename TG>
+__global__ __launch_bounds__(256) void rescale_unless_kernel(TG* __restrict__ x, long n4,
+                                                             const float* __restrict__ upstream, float expected) {
+    const float up = upstream[0];
+    if (up == expected) return;
+    const float f = up / expected;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        CtcRowVec<TG> v;
+        v.load(x + 4 * i);
+        ctc_store4<TG>(x + 4 * i, v.get(0) * f, v.get(1) * f, v.get(2) * f, v.get(3) * f);
+    }
+}
+
+extern "C" int athena_rescale_unless(void* x, long n, int dtype, const float* upstream, float expected,
+                                     athena_stream_t stream) {
+    ATHENA_REQUIRE(x && upstream && n >= 0 && n % 4 == 0 && athena_aligned16(x), ATHENA_E_SHAPE,
+                   "athena_rescale_unless: null operand, n %% 4 != 0 or misaligned");
+    ATHENA_REQUIRE(dtype == ATHENA_F32 || dtype == ATHENA_BF16, ATHENA_E_UNSUPPORTED, "athena_rescale_unless: dtype");
+    ATHENA_REQUIRE(expected != 0.f, ATHENA_E_SHAPE, "athena_rescale_unless: expected factor must not be zero");
+    if (n == 0) return ATHENA_OK;
+    const long n4 = n / 4;
+    const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    if (dtype == ATHENA_BF16)
+        hipLaunchKernelGGL(rescale_unless_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n4,
+                           upstream, expected);
+    else
+        hipLaunchKernelGGL(rescale_unless_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, n4,
+                           upstream, expected);
+    ATHENA_CHECK_LAUNCH("athena_rescale_unless");
     return ATHENA_OK;
 }
 
@@ -920,8 +1412,8 @@ extern "C" int athena_ctc_loss_bwd(const void* logits, int logits_dtype, int ldl
     if (chunk > CTC_OCC_CHUNK) chunk = CTC_OCC_CHUNK;
 #define CTC_GRAD(TL, TG)                                                                                          \
     hipLaunchKernelGGL((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), chunk * sizeof(float), s,                \
-                       (const TL*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.Sp, ws.lse,       \
-                       ws.alpha, ws.beta, ws.flags, grad_scale, host_scale, (TG*)grad, rows, chunk)
+                       (const TL*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.Up, ws.lse,       \
+                       ws.occ, ws.flags, grad_scale, host_scale, (TG*)grad, rows, chunk)
     if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CTC_GRAD(float, float);
     else if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_BF16) CTC_GRAD(float, bf16_t);
     else if (logits_dtype == ATHENA_BF16 && grad_dtype == ATHENA_BF16) CTC_GRAD(bf16_t, bf16_t);

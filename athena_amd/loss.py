@@ -24,8 +24,13 @@ def _as_padded_rows(logits):
 
 
 class _CTCLossFn(torch.autograd.Function):
+    """``upstream`` (a host float or None) is the factor the caller expects this loss to receive in the
+    backward pass -- the weight of the CTC term in the total loss.  With it the forward pass leaves the
+    gradient too, in the same pass over the logits (athena_ctc_loss_fwd_bwd), and the backward pass only
+    corrects it on the device should the factor that arrives differ."""
+
     @staticmethod
-    def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False):
+    def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False, upstream=None):
         B, T, V = logits.shape
         ctx.bf16_grad = bf16_grad
         U = labels.shape[1]
@@ -37,7 +42,15 @@ class _CTCLossFn(torch.autograd.Function):
         per = torch.empty(B, dtype=torch.float32, device=logits.device)
         # the pass over the rows also leaves the per-frame arg-max (zero beyond logit_length)
         best = torch.zeros(B * T, dtype=torch.int32, device=logits.device)
-        ops.ctc_loss_fwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws, argmax=best)
+        ctx.grad = None
+        if upstream and logits.requires_grad and torch.is_grad_enabled():
+            gdt = torch.bfloat16 if bf16_grad else torch.float32
+            ctx.grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
+            ctx.upstream = float(upstream)
+            ops.ctc_loss_fwd_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws,
+                                 ctx.upstream / B, ctx.grad, argmax=best)
+        else:
+            ops.ctc_loss_fwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, per, ws, argmax=best)
         out = torch.empty(1, dtype=torch.float32, device=logits.device)
         ops.group_sum(per, 1, B, 1.0 / B, out)          # tf.reduce_mean over the batch
         ctx.saved = (src, ldl, labels, label_len, logit_len, ws)
@@ -51,12 +64,16 @@ class _CTCLossFn(torch.autograd.Function):
         src, ldl, labels, label_len, logit_len, ws = ctx.saved
         B, T, V, U, blank = ctx.dims
         gs = gout.to(torch.float32).reshape(1).contiguous()
-        gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
-        grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
-        ops.ctc_loss_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, gs, 1.0 / B, grad, ws)
+        if ctx.grad is not None:
+            grad = ctx.grad
+            ops.rescale_unless(grad, gs, ctx.upstream)
+        else:
+            gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
+            grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
+            ops.ctc_loss_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, gs, 1.0 / B, grad, ws)
         if ctx.bf16_grad:
-            return ops.bf16_grad_standin((B, T, V), grad), None, None, None, None, None
-        return grad[..., :V], None, None, None, None, None
+            return ops.bf16_grad_standin((B, T, V), grad), None, None, None, None, None, None
+        return grad[..., :V], None, None, None, None, None, None
 
 
 class CTCLoss:
@@ -70,13 +87,16 @@ class CTCLoss:
         self.logits_time_major = logits_time_major
         self.blank_index = blank_index
         self.need_logit_length = True
+        self.takes_upstream = True
 
-    def __call__(self, logits, samples, logit_length=None):
+    def __call__(self, logits, samples, logit_length=None, upstream=None):
+        """``upstream``: the weight this loss will carry in the total loss, if the caller knows it (a
+        host float); the gradient is then produced together with the loss."""
         assert logit_length is not None
         V = logits.shape[-1]
         blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
         loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank,
-                                      ops.bf16_grad_wanted(logits))
+                                      ops.bf16_grad_wanted(logits), upstream)
         # CTCAccuracy on the same logits and lengths picks this up instead of a second pass over them
         logits._athena_ctc_argmax = (best, logits._version, logit_length)
         return loss

@@ -26,7 +26,11 @@ class BaseModel(nn.Module):
             loss = 0.0
         else:
             logit_length = self.compute_logit_length(samples)
-            loss = self.loss_function(outputs, samples, logit_length)
+            if getattr(self.loss_function, "takes_upstream", False):
+                # this loss is the whole objective: its gradient arrives with factor 1
+                loss = self.loss_function(outputs, samples, logit_length, upstream=1.0)
+            else:
+                loss = self.loss_function(outputs, samples, logit_length)
         if self.metric is None:
             metrics = {}
         else:

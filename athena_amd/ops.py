@@ -751,6 +751,35 @@ def ctc_loss_fwd(logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, l
                "athena_ctc_loss_fwd")
 
 
+def ctc_loss_fwd_bwd(logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, loss, workspace, grad_scale,
+                     grad, argmax=None):
+    """Loss and gradient in one pass over the logits: ``grad`` [B,T,ldl] = grad_scale * (softmax - occupancy)."""
+    lib = _lib.load()
+    if argmax is not None and (argmax.dtype != torch.int32 or argmax.numel() < B * T or not argmax.is_contiguous()):
+        raise RuntimeError("athena_amd.ctc_loss: argmax must be contiguous int32 [B*T]")
+    for t_ in (labels, label_len, logit_len):
+        if t_.dtype != torch.int32 or not t_.is_contiguous():
+            raise RuntimeError("athena_amd.ctc_loss: labels and lengths must be contiguous int32")
+    if labels.numel() != B * U or label_len.numel() != B or logit_len.numel() != B or loss.numel() != B:
+        raise RuntimeError("athena_amd.ctc_loss: bad label shapes")
+    if grad.numel() != B * T * ldl or not grad.is_contiguous():
+        raise RuntimeError("athena_amd.ctc_loss: grad must be contiguous [B,T,ldl]")
+    _lib.check(lib.athena_ctc_loss_fwd_bwd(_ptr(logits), dt(logits), ldl, _ptr(labels), _ptr(label_len),
+                                           _ptr(logit_len), B, T, V, U, blank, _ptr(loss), _ptr(argmax),
+                                           float(grad_scale), _ptr(grad), dt(grad), _ptr(workspace),
+                                           workspace.numel() * workspace.element_size(), _stream()),
+               "athena_ctc_loss_fwd_bwd")
+
+
+def rescale_unless(x, upstream, expected):
+    """x *= upstream / expected on the device, a no-op launch when the two are equal."""
+    lib = _lib.load()
+    if upstream.dtype != torch.float32 or upstream.numel() != 1 or not x.is_contiguous() or x.numel() % 4:
+        raise RuntimeError("athena_amd.rescale_unless: bad operands")
+    _lib.check(lib.athena_rescale_unless(_ptr(x), x.numel(), dt(x), _ptr(upstream), float(expected), _stream()),
+               "athena_rescale_unless")
+
+
 def ctc_loss_bwd(logits, ldl, labels, label_len, logit_len, B, T, V, U, blank, grad_scale, host_scale, grad,
                  workspace):
     lib = _lib.load()

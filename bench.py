@@ -209,7 +209,7 @@ GEMM_ENTRIES = ["athena_gemm", "athena_gemm_grouped", "athena_gemm_wgrad_table",
                 "athena_layer_tail_bwd", "athena_conv3x3s2_fwd", "athena_conv3x3s2_dgrad", "athena_conv3x3s2_wgrad"]
 GEMM_FAMILIES = ("conv2", "layer_gemm", "vocab", "dense_wgrad")
 ATTN_ENTRIES = ["athena_mha_fwd", "athena_mha_bwd"]
-CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd"]
+CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd", "athena_ctc_loss_fwd_bwd", "athena_rescale_unless"]
 
 
 def _cpu_model():
@@ -460,7 +460,8 @@ def main():
         if prof_ms is not None:
             c_ms = max(c_ms, prof_ms * nrep)
         cb = ctc_bytes(wl) * nrep / (c_ms * 1e-3) / 1e9
-        ctc_roof = {"kernel": "ctc_fwd_kernel (row logsumexp + lattice) + ctc_finish + ctc_grad", "bound": "hbm",
+        ctc_roof = {"kernel": "ctc_row_kernel (logsumexp, emissions, dense gradient) + ctc_lattice_kernel + ctc_post_kernel "
+                              "(+ rescale_unless_kernel in the backward pass)", "bound": "hbm",
                     "achieved": cb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cb / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(args.workload, "ctc"),
                     "ms_per_step": c_ms / nrep, "bytes_per_step": ctc_bytes(wl)}

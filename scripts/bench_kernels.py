@@ -154,7 +154,12 @@ def bench_ctc():
         grad = torch.empty_like(logits)
         t1 = timeit(lambda: ops.ctc_loss_fwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, per, ws))
         t2 = timeit(lambda: ops.ctc_loss_bwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, None, 1.0 / B, grad, ws))
+        g16 = torch.empty(B, T, ldl, device=dev, dtype=torch.bfloat16)
+        t3 = timeit(lambda: ops.ctc_loss_fwd_bwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, per, ws, 1.0 / B, g16))
+        t4 = timeit(lambda: ops.ctc_loss_fwd_bwd(logits, ldl, labels, ll, tl, B, T, V, U, V - 1, per, ws, 1.0 / B, grad))
         by = B * T * V * 4
+        print("one pass, bf16 gradient %8.1f us (%6.0f GB/s of the %d MB two passes would move)   fp32 gradient %8.1f us" %
+              (t3 * 1e6, 2.5 * by / t3 / 1e9, int(2.5 * by) >> 20, t4 * 1e6))
         print("fwd %8.1f us (%6.0f GB/s read)   bwd %8.1f us (%6.0f GB/s r+w)   total %6.0f GB/s of %d MB" %
               (t1 * 1e6, by / t1 / 1e9, t2 * 1e6, 2 * by / t2 / 1e9, 3 * by / (t1 + t2) / 1e9, 3 * by >> 20))
 

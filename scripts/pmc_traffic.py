@@ -14,7 +14,7 @@ from collections import defaultdict
 FAMILIES = {
     "gemm": ("gemm_mfma", "gemm_big", "layer_tail", "splitk_reduce"),
     "attention": ("mha_",),
-    "ctc": ("ctc_",),
+    "ctc": ("ctc_", "rescale_unless"),
 }
 
 

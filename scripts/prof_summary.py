@@ -26,7 +26,7 @@ def main(path, steps):
     # kernel families as bench.py groups them (C-ABI entry points)
     fams = [("GEMM cores (gemm_mfma*, gemm_big*, layer_tail*, splitk_reduce*)", ("gemm_mfma", "gemm_big", "layer_tail", "splitk_reduce")),
             ("attention (mha_*)", ("mha_",)),
-            ("CTC (ctc_*)", ("ctc_",))]
+            ("CTC (ctc_*, rescale_unless*)", ("ctc_", "rescale_unless"))]
     print()
     print("%-50s %10s %14s %12s" % ("family", "calls/step", "ms per step", "avg_us"))
     for label, keys in fams:

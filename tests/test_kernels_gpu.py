@@ -715,6 +715,136 @@ def test_ctc_infeasible_matches_tf_dense(ops):
         assert_close(grad[b], grad_ref[b], 1e-4, "ctc grad, TF dense semantics (long), sample %d" % b)
 
 
+def _run_ctc_fused(ops, logits, labels, llen, tlen, gscale=1.0, grad_dtype=torch.float32):
+    """(per-sample loss, gradient [B,T,V], arg-max) of the one-pass entry point on fp32 logits [B,T,V]."""
+    B, T, V = logits.shape
+    U = labels.shape[1]
+    ldl = (V + 7) // 8 * 8
+    buf = torch.zeros(B, T, ldl, dtype=torch.float32, device=dev())
+    buf[..., :V] = torch.as_tensor(logits).float().to(dev())
+    ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=dev())
+    per = torch.empty(B, dtype=torch.float32, device=dev())
+    lab_d = torch.as_tensor(labels, dtype=torch.int32).to(dev())
+    ll_d = torch.as_tensor(llen, dtype=torch.int32).to(dev())
+    tl_d = torch.as_tensor(tlen, dtype=torch.int32).to(dev())
+    grad = torch.full((B, T, ldl), float("nan"), dtype=grad_dtype, device=dev())
+    best = torch.full((B * T,), -7, dtype=torch.int32, device=dev())
+    ops.ctc_loss_fwd_bwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, U, V - 1, per, ws, gscale, grad, argmax=best)
+    if ldl > V:
+        assert float(grad[..., V:].float().abs().max()) == 0.0
+    return per, grad[..., :V], best.view(B, T)
+
+
+@pytest.mark.parametrize("B,T,V,U", [(3, 12, 7, 4), (4, 40, 30, 9), (2, 150, 50, 40), (5, 64, 4233, 20),
+                                     (2, 90, 101, 33), (2, 300, 60, 100), (1, 250, 40, 200), (2, 30, 12, 0),
+                                     (2, 20, 9000, 6)])
+def test_ctc_one_pass_loss_and_grad(ops, B, T, V, U):
+    """athena_ctc_loss_fwd_bwd (loss and gradient from one pass over the logits) against the textbook
+    recursion, with repeated labels (several lattice states sharing a logits column), ragged lengths,
+    rows wider than the register path, and against the two-call path."""
+    Ue = max(U, 1)
+    logits, labels, llen, tlen = _ctc_case(B, T, V, Ue, seed=B * 1000 + T + U)
+    if U == 0:
+        llen[:] = 0
+        labels[:] = 0
+    if U >= 4:
+        labels[0, 3] = labels[0, 0]          # a repeat that is not adjacent
+    lt = torch.from_numpy(logits).float()
+    loss_ref, grad_ref = octc.ctc_loss_textbook(lt.double().numpy(), labels, llen, tlen, blank_index=-1)
+    per, grad, best = _run_ctc_fused(ops, lt, labels, llen, tlen, gscale=0.7 / B)
+    assert_close(per, loss_ref, 1e-5, "ctc loss (one pass)")
+    assert_close(grad, 0.7 * grad_ref / B, 1e-4, "ctc grad (one pass)")
+    want = lt.argmax(-1)
+    for b in range(B):
+        assert best[b, :tlen[b]].cpu().tolist() == want[b, :tlen[b]].tolist()
+        if tlen[b] < T:
+            assert float(grad[b, tlen[b]:].abs().max()) == 0.0
+    per2, grad2 = _run_ctc(ops, lt, labels, llen, tlen, gscale=0.7 / B)
+    assert torch.equal(per, per2)
+    assert_close(grad, grad2.double(), 1e-6, "one pass against two calls")
+    # bf16 gradient: the same values rounded once
+    _, g16, _ = _run_ctc_fused(ops, lt, labels, llen, tlen, gscale=0.7 / B, grad_dtype=torch.bfloat16)
+    assert_close(g16.float(), grad.to(torch.bfloat16).float().double(), 1e-2, "bf16 gradient (one pass)")
+
+
+def test_ctc_one_pass_infeasible_matches_tf_dense(ops):
+    """Samples without a fitting alignment through the one-pass entry point: TensorFlow's dense-branch
+    loss and gradient (the slow path writes the gradient columns itself)."""
+    rng = np.random.default_rng(11)
+    B, T, V, U = 6, 7, 6, 5
+    logits = np.float32(rng.normal(size=(B, T, V)) * 1.5)
+    labels = np.array([[1, 2, 3, 1, 2], [2, 2, 2, 0, 0], [1, 3, 0, 0, 0], [4, 4, 1, 1, 0], [3, 1, 2, 0, 0],
+                       [0, 0, 0, 0, 0]], dtype=np.int32)
+    llen = np.array([5, 3, 2, 4, 3, 0], np.int32)
+    tlen = np.array([3, 4, 7, 5, 0, 0], np.int32)
+    loss_ref, grad_ref = octc.ctc_loss_tf_dense(logits.astype(np.float64), labels, llen, tlen, blank_index=-1)
+    per, grad, _ = _run_ctc_fused(ops, logits, labels, llen, tlen)
+    assert_close(per, loss_ref, 1e-5, "ctc loss, TF dense semantics (one pass)")
+    for b in range(B):
+        if tlen[b] > 0:
+            assert_close(grad[b], grad_ref[b], 1e-4, "ctc grad, TF dense semantics (one pass), sample %d" % b)
+        else:
+            assert float(grad[b].abs().max()) == 0.0
+    B, T, V, U = 2, 60, 40, 70
+    logits = np.float32(rng.normal(size=(B, T, V)) * 2.0)
+    labels = rng.integers(1, V - 1, size=(B, U)).astype(np.int32)
+    llen = np.array([70, 20], np.int32)
+    labels[1, 20:] = 0
+    tlen = np.array([60, 60], np.int32)
+    loss_ref, grad_ref = octc.ctc_loss_tf_dense(logits.astype(np.float64), labels, llen, tlen, blank_index=-1)
+    per, grad, _ = _run_ctc_fused(ops, logits, labels, llen, tlen)
+    assert_close(per, loss_ref, 1e-5, "ctc loss, TF dense semantics (one pass, long)")
+    for b in range(B):
+        assert_close(grad[b], grad_ref[b], 1e-4, "ctc grad, TF dense semantics (one pass, long), sample %d" % b)
+
+
+def test_ctc_extreme_logits_fall_back_to_the_log_domain(ops):
+    """Emissions beyond what the probability-domain recursion holds (a label 400 nats below blank on
+    the only path): the sample is redone on logarithms and still matches the oracle."""
+    rng = np.random.default_rng(3)
+    B, T, V, U = 2, 6, 5, 3
+    logits = np.float32(rng.normal(size=(B, T, V)))
+    logits[0, :, 1] -= 400.0
+    labels = np.array([[1, 2, 1], [2, 3, 0]], np.int32)
+    llen = np.array([3, 2], np.int32)
+    tlen = np.array([6, 6], np.int32)
+    loss_ref, grad_ref = octc.ctc_loss_tf_dense(logits.astype(np.float64), labels, llen, tlen, blank_index=-1)
+    per, grad, _ = _run_ctc_fused(ops, logits, labels, llen, tlen)
+    assert torch.isfinite(per).all()
+    assert_close(per, loss_ref, 1e-5, "ctc loss with extreme logits")
+    assert_close(grad, grad_ref, 1e-4, "ctc grad with extreme logits")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rescale_unless(ops, dtype):
+    x = torch.randn(5, 1000, device=dev()).to(dtype)
+    keep = x.clone()
+    up = torch.tensor([0.5], dtype=torch.float32, device=dev())
+    ops.rescale_unless(x, up, 0.5)
+    assert torch.equal(x, keep)
+    ops.rescale_unless(x, up, 0.25)
+    assert_close(x.float(), (keep.float() * 2.0).double(), 1e-6, "rescale")
+
+
+def test_ctc_loss_function_with_expected_upstream():
+    """CTCLoss(upstream=w): the gradient written in the forward pass equals the two-call gradient, and
+    an upstream factor other than the expected one is corrected in the backward pass."""
+    from athena_amd.loss import CTCLoss
+    B, T, V, U = 3, 30, 20, 6
+    logits, labels, llen, tlen = _ctc_case(B, T, V, U, seed=77)
+    samples = {"output": torch.from_numpy(labels).to(dev()), "output_length": torch.from_numpy(llen).to(dev())}
+    tl = torch.from_numpy(tlen).to(dev())
+    grads = []
+    for upstream, factor in ((None, 0.3), (0.3, 0.3), (0.3, 1.1)):
+        x = torch.from_numpy(logits).float().to(dev()).requires_grad_(True)
+        loss = CTCLoss(blank_index=-1)(x, samples, tl, upstream=upstream)
+        (loss * factor).backward()
+        grads.append((float(loss), x.grad.clone()))
+    assert grads[0][0] == grads[1][0] == grads[2][0]
+    assert_close(grads[1][1], grads[0][1].double(), 1e-6, "gradient written with the loss")
+    assert_close(grads[2][1], grads[0][1].double() * (1.1 / 0.3), 1e-6, "gradient corrected in the backward pass")
+
+
 def test_ctc_label_row_too_long_is_refused(ops):
     """Label rows beyond 2U+1 = 1024 lattice states are refused with a clear error, not truncated."""
     B, T, V, U = 1, 8, 16, 600
