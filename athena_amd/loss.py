@@ -43,7 +43,7 @@ class _CTCLossFn(torch.autograd.Function):
         # the pass over the rows also leaves the per-frame arg-max (zero beyond logit_length)
         best = torch.zeros(B * T, dtype=torch.int32, device=logits.device)
         ctx.grad = None
-        if upstream and logits.requires_grad and torch.is_grad_enabled():
+        if upstream and ctx.needs_input_grad[0]:
             gdt = torch.bfloat16 if bf16_grad else torch.float32
             ctx.grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
             ctx.upstream = float(upstream)
@@ -66,7 +66,10 @@ class _CTCLossFn(torch.autograd.Function):
         gs = gout.to(torch.float32).reshape(1).contiguous()
         if ctx.grad is not None:
             grad = ctx.grad
-            ops.rescale_unless(grad, gs, ctx.upstream)
+            # inside a solver step the factor that arrives is the one the model announced; anywhere
+            # else it is compared on the device and the gradient corrected if it differs
+            if not ops.root_gradient_is_one():
+                ops.rescale_unless(grad, gs, ctx.upstream)
         else:
             gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
             grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)

@@ -903,7 +903,9 @@ _HANDOVER_DEPTH = 0
 
 
 class bf16_grad_handover:
-    """Context in which the loss functions may hand bf16 gradients to the vocabulary projections."""
+    """Context of a solver's training step: the loss functions may hand bf16 gradients to the vocabulary
+    projections (nothing else looks at the gradient of the logits), and the backward pass starts from
+    ``total_loss.backward()``, i.e. from a gradient of exactly 1 at the total loss."""
 
     def __enter__(self):
         global _HANDOVER_DEPTH
@@ -914,6 +916,12 @@ class bf16_grad_handover:
         global _HANDOVER_DEPTH
         _HANDOVER_DEPTH -= 1
         return False
+
+
+def root_gradient_is_one():
+    """True inside a solver step, where the factor a loss term receives in the backward pass is the
+    weight the model gave it in the total loss and nothing else."""
+    return _HANDOVER_DEPTH > 0
 
 
 def bf16_grad_wanted(logits):

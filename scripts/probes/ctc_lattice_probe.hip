@@ -1,4 +1,5 @@
-// Times ctc_lattice_kernel<R> alone on a synthetic emission table (hipcc -DPROBE_R=2 [-DCTC_PROBE_...]).
+// Times ctc_lattice_kernel alone on a synthetic emission table (every sample has a path, so the slow
+// path and its null operands are never touched) (hipcc -DPROBE_R=2 [-DCTC_PROBE_...]).
 #include "../../athena_amd/csrc/loss.hip"
 #include <cstdio>
 void athena_set_error(const char*, ...) {}
@@ -26,7 +27,9 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL((ctc_lattice_kernel<R>), dim3(B), dim3(256), 0, 0, de, dl, dll, dtl, T, U, da, db, dz);
+            hipLaunchKernelGGL((ctc_lattice_kernel<float, float, R>), dim3(B), dim3(256), 0, 0, de, dl, dll, dtl, T, U, da, db, dz,
+                               (const float*)nullptr, 8, 8, 7, U + 1, (const float*)nullptr, (float*)nullptr,
+                               (const int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0.f, (float*)nullptr);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("R=%d B=%d T=%d: %.1f us per launch, %.0f cycles per step at 2.4 GHz\n", R, B, T, ms * 50.f, ms * 50.f * 2400.f / T);
