@@ -203,8 +203,12 @@ __device__ __forceinline__ void row_regs_load(const float* __restrict__ row, int
         if (c < ld) x[i] = *(const float4*)(row + c);
     }
 }
+// Statistics of a row held in registers behind ONE workgroup barrier: every wave reduces its own part
+// by lane shuffles (maximum, first column holding it, sum of exponentials relative to the wave's
+// maximum), lane 0 of each wave leaves the three numbers in LDS, and behind the barrier every thread
+// combines the four waves' numbers for itself.  ``slot``: 12 floats of LDS.
 __device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V, float& m_out, float& s_out,
-                                               int& arg_out, float* red) {
+                                               int& arg_out, float* slot) {
     float m = -INFINITY;
     int idx = 0x7fffffff;
 #pragma unroll
@@ -222,28 +226,34 @@ __device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V,
             idx = c + (x[i].x == mx ? 0 : x[i].y == mx ? 1 : x[i].z == mx ? 2 : 3);
         }
     }
-    const float gm = block_max(m, red);
+    const float wm = wave_max(m);
     float s = 0.f;
-    if (gm != -INFINITY) {
+    if (wm != -INFINITY) {
 #pragma unroll
         for (int i = 0; i < CTC_ROW_REGS; ++i)
-            s += __expf(x[i].x - gm) + __expf(x[i].y - gm) + __expf(x[i].z - gm) + __expf(x[i].w - gm);
+            s += __expf(x[i].x - wm) + __expf(x[i].y - wm) + __expf(x[i].z - wm) + __expf(x[i].w - wm);
     }
-    // smallest column among the threads that saw the maximum (column indices are exact in fp32)
-    float cand = (m == gm && idx != 0x7fffffff) ? -(float)idx : -INFINITY;
     s = wave_sum(s);
-    cand = wave_max(cand);
+    // smallest column among the lanes that saw the wave's maximum (column indices are exact in fp32)
+    const float cand = wave_max(m == wm && idx != 0x7fffffff ? -(float)idx : -INFINITY);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
     if (lane == 0) {
-        red[w] = s;
-        red[8 + w] = cand;
+        slot[w] = wm;
+        slot[4 + w] = s;
+        slot[8 + w] = cand;
     }
     __syncthreads();
-    s_out = (red[0] + red[1]) + (red[2] + red[3]);
-    const float best = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
-    arg_out = best == -INFINITY ? 0 : (int)(-best);
+    const float gm = fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+    float tot = 0.f, best = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float wk = slot[k];
+        if (wk != -INFINITY) tot += slot[4 + k] * __expf(wk - gm);
+        if (wk == gm) best = fmaxf(best, slot[8 + k]);
+    }
     m_out = gm;
+    s_out = tot;
+    arg_out = best == -INFINITY ? 0 : (int)(-best);
 }
 
 // ---------------------------------------------------------------- lattice arithmetic
@@ -763,6 +773,18 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
     const int lane = threadIdx.x & 63;
     const int dir = (threadIdx.x >> 6) & 1;
     const bool flusher = threadIdx.x >= 128;
+    // label of each of the lane's label states, its predecessor and its successor
+    int lab_c[HR], lab_p[HR], lab_n[HR];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int u = lane * HR + i;
+        lab_c[i] = lab_p[i] = lab_n[i] = 0;
+        if (U > 0) {
+            lab_c[i] = labels[(long)b * U + min(u, U - 1)];
+            lab_p[i] = labels[(long)b * U + min(max(u - 1, 0), U - 1)];
+            lab_n[i] = labels[(long)b * U + min(u + 1, U - 1)];
+        }
+    }
     const int L = min(max(label_len[b], 0), U);
     const int Sb = 2 * L + 1;
     int len = logit_len[b];
@@ -811,18 +833,15 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
         }
     } else {
     __builtin_amdgcn_s_setprio(3);
-    // the skip transitions of each state as factors 0 / 1
+    // the skip transitions of each state as factors 0 / 1 (the labels were requested together with the
+    // lengths, through clamped indices, so that they cost no memory latency of their own)
     double skip_in[R], skip_out[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int s = lane * R + r;
-        bool si = false, so = false;
-        if ((s & 1) && s < Sb) {
-            const int u = s >> 1;
-            const int c = labels[(long)b * U + u];
-            if (u >= 1) si = c != labels[(long)b * U + u - 1];
-            if (s + 2 < Sb) so = labels[(long)b * U + u + 1] != c;
-        }
+        const int u = s >> 1;
+        const bool si = (s & 1) && s < Sb && u >= 1 && lab_c[r >> 1] != lab_p[r >> 1];
+        const bool so = (s & 1) && s + 2 < Sb && lab_n[r >> 1] != lab_c[r >> 1];
         skip_in[r] = si ? 1.0 : 0.0;
         skip_out[r] = so ? 1.0 : 0.0;
     }
