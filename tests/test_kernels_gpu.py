@@ -737,7 +737,9 @@ def _run_ctc_fused(ops, logits, labels, llen, tlen, gscale=1.0, grad_dtype=torch
 
 @pytest.mark.parametrize("B,T,V,U", [(3, 12, 7, 4), (4, 40, 30, 9), (2, 150, 50, 40), (5, 64, 4233, 20),
                                      (2, 90, 101, 33), (2, 300, 60, 100), (1, 250, 40, 200), (2, 30, 12, 0),
-                                     (2, 20, 9000, 6)])
+                                     (2, 20, 9000, 6), (2, 1, 5, 1), (3, 2, 6, 1),
+                                     # every lattice size the library is built for: 2U+1 states on 64 lanes
+                                     (1, 320, 30, 150), (2, 650, 20, 300), (1, 950, 20, 450), (1, 1030, 12, 511)])
 def test_ctc_one_pass_loss_and_grad(ops, B, T, V, U):
     """athena_ctc_loss_fwd_bwd (loss and gradient from one pass over the logits) against the textbook
     recursion, with repeated labels (several lattice states sharing a logits column), ragged lengths,
