@@ -346,6 +346,95 @@ class _PipelinedGraphStep:
         return self.loss, self.metrics
 
 
+class _OneGraphPipelinedStep:
+    """The data-parallel step as ONE HIP graph with the gradient exchange inside it.
+
+    Same cuts of the backward pass as _PipelinedGraphStep (decoder | encoder thirds | front end), but
+    the all-reduce of each finished range is recorded where it is issued, on a side stream: RCCL's
+    kernels become nodes of the graph, a branch beside the pieces of the backward pass that follow,
+    joined in front of the update.  One graph launch per step instead of six, so the step costs what
+    the single-process step costs plus whatever of the last exchange is not hidden, however slow the
+    host is.  The collectives go through the solver's own communicator (utils/rccl.py): one issued
+    through torch.distributed cannot be recorded safely, its watchdog thread polls events that were
+    recorded while capturing."""
+
+    def __init__(self, solver, samples):
+        self.solver = solver
+        store = solver.model.store
+        self.inputs = {k: v.clone() for k, v in samples.items()}
+        metrics_objs = solver._metric_objects()
+        before = [len(m._pending) for m in metrics_objs]
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        grads = store.grads
+        step = max(int(solver.BUCKET_MB * (1 << 20) / 4), 1)
+        works = []
+
+        def exchange(a, b):
+            for lo in range(a, b, step):
+                works.append(solver._exchange_async(grads[lo:min(lo + step, b)]))
+
+        store.collect_cuts = True
+        store.shadows_dirty = True          # the refresh is always part of the recorded forward pass
+        try:
+            with _capture(self.graph, solver._graph_pool()), ops.bf16_grad_handover():
+                outputs = solver.model(self.inputs, training=True)
+                self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
+                total = sum(list(self.loss.values())) if isinstance(self.loss, dict) else self.loss
+                cuts = dict(store.cuts)
+                enc_cuts = [t for t, _ in store.cuts if t.startswith("encoder.")]          # forward order
+                ranges = _piece_ranges(store, [int(t.split(".")[1]) for t in enc_cuts])
+                g_mem, g_y = torch.autograd.grad(total, [cuts["memory"], cuts["y_net"]], retain_graph=True)
+                exchange(*ranges[0])
+                up, g_up = cuts["memory"], g_mem
+                for k, tag in enumerate(reversed(enc_cuts)):
+                    (g_dn,) = torch.autograd.grad([up], [cuts[tag]], [g_up], retain_graph=True)
+                    exchange(*ranges[1 + k])
+                    up, g_up = cuts[tag], g_dn
+                torch.autograd.backward([up, cuts["y_net"]], [g_up, g_y])
+                exchange(*ranges[-1])
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                solver._update(1.0 / max(solver.world_size, 1))
+        finally:
+            store.collect_cuts = False
+            store.cuts = []
+        self._keep = (cuts, g_mem, g_y, up, g_up)          # the graph's buffers must outlive it
+        self.templates = []
+        for m, n in zip(metrics_objs, before):
+            self.templates.append((m, m._pending[n:]))
+            del m._pending[n:]
+
+    def run(self, samples):
+        from .metrics import _Deferred
+        for k, v in self.inputs.items():
+            v.copy_(samples[k], non_blocking=True)
+        self.graph.replay()
+        self.solver.model.store.shadows_dirty = True
+        for m, items in self.templates:
+            for t in items:
+                m._pending.append(_Deferred(t.owner, list(t.tensors), t.score).to_host())
+        return self.loss, self.metrics
+
+
+class _StreamHandle:
+    """Handle of a collective enqueued on a side stream: ``wait`` makes the current stream wait for it."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def _encoder_cut_layers(store):
+    """The encoder layers behind which the backward pass is cut (the rule of
+    layers/transformer.py: thirds of a stack of three or more layers), from the parameter names."""
+    n = 1 + max([int(s.name.split(".")[1]) for s in store.train_slots if s.name.startswith("encoder.")], default=-1)
+    return [k for k in range(1, n) if n >= 3 and k % ((n + 2) // 3) == 0]
+
+
 def _piece_ranges(store, enc_cut_layers):
     """Ranges of the flat gradient buffer that are final after each backward piece, in replay order:
     [decoder + heads], [encoder layers >= last cut], ..., [front end, y_net, first encoder layers].
@@ -423,6 +512,19 @@ class HorovodSolver(BaseSolver):
         # ATHENA_FORCE_DP=1 runs the exchange (and the two-graph step) even with one rank: a way to
         # exercise the RCCL path on a single GPU
         self._force_exchange = os.environ.get("ATHENA_FORCE_DP", "0") == "1" and dist.is_initialized()
+        # The solver's own RCCL communicator (utils/rccl.py): collectives issued through it can be
+        # recorded in a HIP graph.  Created here, where every rank is at the same point, and checked
+        # against the process group; None where it cannot be had (another backend, a failed check).
+        self._rccl, self._side, self._plan = None, None, None
+        if (self.world_size > 1 or self._force_exchange) and dist.is_initialized() and dist.get_backend() == "nccl" \
+                and os.environ.get("ATHENA_DP_OWN_COMM", "1") != "0":
+            try:
+                from .utils.rccl import Communicator
+                comm = Communicator()
+                comm.self_test()
+                self._rccl = comm
+            except Exception as e:      # noqa: BLE001 -- any failure means: collectives through torch.distributed
+                logging.warning("own RCCL communicator unavailable (%s): gradient exchange between graphs", e)
 
     @staticmethod
     def initialize_devices(solver_gpus=None):
@@ -452,7 +554,14 @@ class HorovodSolver(BaseSolver):
         self._broadcast_done = True
 
     def _exchange_async(self, t):
-        """Start the sum of a slice of the flat gradient buffer over the ranks; returns the handle."""
+        """Start the sum of a slice of the flat gradient buffer over the ranks; returns a handle whose
+        ``wait`` makes the current stream wait for the result."""
+        if self._rccl is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())      # the slice is final on the launch stream
+            self._rccl.all_reduce_sum_(t, self._side)
+            return _StreamHandle(self._side)
         if t.is_cuda and dist.get_backend() == "gloo":
             # rehearsal of the multi-rank step on a box with fewer GPUs than ranks: gloo sums on the host
             host = t.cpu()
@@ -461,23 +570,53 @@ class HorovodSolver(BaseSolver):
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
+    def _exchange_plan(self):
+        """The slices of the flat gradient buffer in the order every kind of step exchanges them: the
+        ranges that become final piece by piece in the backward pass (decoder and heads, encoder thirds
+        from the top, front end), each in buckets of BUCKET_MB.  Ranks may be in different kinds of step
+        at the same time (one replaying a recorded shape, another meeting a new shape eagerly): the
+        collectives pair up only because all of them follow this one list."""
+        if self._plan is None:
+            st = self.model.store
+            step = max(int(self.BUCKET_MB * (1 << 20) / 4), 1)
+            try:
+                ranges = _piece_ranges(st, _encoder_cut_layers(st))
+            except (RuntimeError, KeyError, AttributeError, ValueError, IndexError):
+                ranges = [(0, st.n_train)]      # a parameter layout without that shape: one range
+            self._plan = [(lo, min(lo + step, b)) for a, b in ranges for lo in range(a, b, step)]
+        return self._plan
+
     def _reduce_gradients(self):
-        """Sum the flat gradient buffer over ranks bucket by bucket; the 1/world_size of the
-        average is folded into the optimizer kernel."""
+        """Sum the flat gradient buffer over ranks, slice by slice of the exchange plan; the
+        1/world_size of the average is folded into the optimizer kernel."""
         if self.world_size == 1 and not self._force_exchange:
             return 1.0
         g = self.model.store.grads
-        works = [self._exchange_async(g[a:b]) for a, b in self._buckets]
+        works = [self._exchange_async(g[a:b]) for a, b in self._exchange_plan()]
         for w in works:
             if w is not None:
                 w.wait()
         return 1.0 / self.world_size
 
     def _record(self, samples):
-        # With more than one rank the exchange runs behind the backward pass, piece by piece
-        # (ATHENA_DP_PIPELINE=0: one exchange after the whole backward pass instead).  With a single
-        # rank the extra graph boundaries cost 0.2 ms of a 6 ms AISHELL step and hide nothing.
-        if (self.world_size > 1 or self._force_exchange) and os.environ.get("ATHENA_DP_PIPELINE", "1") != "0":
+        # With more than one rank the exchange runs behind the backward pass, piece by piece.
+        # ATHENA_DP_MODE picks how: "onegraph" (the default on RCCL: the pieces and their exchanges in
+        # ONE HIP graph), "pipelined" (a chain of graphs with the collectives issued between them through
+        # torch.distributed; what remains when the own communicator cannot be had), "split" (two graphs
+        # around one exchange; also ATHENA_DP_PIPELINE=0).  With a single rank and no forced exchange
+        # the plain single graph is recorded.
+        dp = self.world_size > 1 or self._force_exchange
+        mode = os.environ.get("ATHENA_DP_MODE", "")
+        if not mode:
+            mode = "split" if os.environ.get("ATHENA_DP_PIPELINE", "1") == "0" else "onegraph"
+        if dp and mode == "onegraph":
+            if self._rccl is not None:
+                try:
+                    return _OneGraphPipelinedStep(self, samples)
+                except RuntimeError as e:      # unusual parameter layout, a collective that cannot be recorded
+                    logging.warning("one-graph gradient exchange disabled: %s", e)
+            mode = "pipelined"
+        if dp and mode == "pipelined":
             try:
                 return _PipelinedGraphStep(self, samples)
             except RuntimeError as e:          # unusual parameter layout: exchange after the whole backward pass

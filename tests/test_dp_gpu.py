@@ -72,3 +72,39 @@ def test_two_ranks_pipelined_exchange_matches_hand_averaged_gradients(tmp_path):
         if s.name.endswith(ZERO_GRAD):
             skip[s.offset:s.offset + s.numel] = True
     assert rel_err(got["params"].double()[~skip], want[~skip]) <= 1e-4
+
+
+def test_one_rank_on_rccl_records_the_exchange_in_the_step_graph(tmp_path):
+    """With RCCL as the backend the data-parallel step is ONE graph: the pieces of the backward pass with
+    the all-reduce of each finished range recorded beside them, through the solver's own communicator
+    (utils/rccl.py, whose self-test compares it with the process group eagerly and under replay).  One
+    rank is all a one-GPU box can hold on RCCL; its trajectory must be the single-process one."""
+    from athena_amd import BaseSolver, WarmUpAdam
+    steps = 4
+    case = dict(TINY, mc=model_config(32, 16, 4, 3, 1, 64, rate=0.0), B=4)
+    opt_cfg = dict(d_model=32, warmup_steps=3, k=0.05, decay_steps=100000, decay_rate=1.0)
+    out_path = str(tmp_path / "rccl.pt")
+    ctx = multiprocessing.get_context("forkserver")
+    p = ctx.Process(target=dp_worker.run_single_rank_rccl, args=(_free_port(), case, "fp32", opt_cfg, steps, out_path))
+    p.start()
+    p.join(timeout=240)
+    if p.is_alive():
+        p.kill()
+        raise AssertionError("the rank did not finish")
+    assert p.exitcode == 0, p.exitcode
+    got = torch.load(out_path, weights_only=True)
+    assert got["own_communicator"] and got["onegraph"]
+
+    model, samples, _ = build(case, "fp32")
+    st = model.store
+    solver = BaseSolver(model, WarmUpAdam(dict(opt_cfg)), config={"clip_norm": 0.5, "enable_tf_function": False})
+    ds = model.prepare_samples(samples)
+    losses = [float(solver.train_step(ds)[0]) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in zip(got["losses"], losses):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (got["losses"], losses)
+    skip = torch.zeros(st.n_train, dtype=torch.bool)
+    for s in st.train_slots:
+        if s.name.endswith(ZERO_GRAD):
+            skip[s.offset:s.offset + s.numel] = True
+    assert rel_err(got["params"].double()[~skip], st.params[:st.n_train].double().cpu()[~skip]) <= 1e-4

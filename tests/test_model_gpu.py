@@ -246,11 +246,11 @@ def test_data_parallel_step_structure_on_one_gpu():
     case = dict(TINY, mc=model_config(32, 16, 4, 3, 1, 64, rate=0.1))     # 3 encoder layers: two encoder cuts
     opt_cfg = dict(d_model=32, warmup_steps=3, k=0.05, decay_steps=100000, decay_rate=1.0)
     out = {}
-    for mode in ("single", "dp_eager", "dp_graph", "dp_graph_unpipelined"):
+    for mode in ("single", "dp_eager", "dp_graph", "dp_graph_unpipelined", "dp_onegraph"):
         os.environ["ATHENA_DP_PIPELINE"] = "0" if mode == "dp_graph_unpipelined" else "1"
         model, samples, _ = build(case, "fp32")
         opt = WarmUpAdam(dict(opt_cfg))
-        cfg = {"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": mode.startswith("dp_graph")}
+        cfg = {"clip_norm": 0.5, "log_interval": 1, "enable_tf_function": mode.startswith("dp_graph") or mode == "dp_onegraph"}
         if mode == "single":
             solver = BaseSolver(model, opt, config=cfg)
         else:
@@ -260,7 +260,16 @@ def test_data_parallel_step_structure_on_one_gpu():
             def fake_exchange(t):
                 t.mul_(2.0)                     # sum over two ranks holding the same gradients
                 return None
-            solver._exchange_async = fake_exchange
+            if mode != "dp_onegraph":
+                solver._exchange_async = fake_exchange
+            else:
+                # the pieces of the backward pass and their exchanges recorded in ONE graph, the exchanges
+                # on a side stream through the solver's own communicator (here: a stand-in for it)
+                class SameGradientsOnTheOtherRank:
+                    def all_reduce_sum_(self, t, stream=None):
+                        with torch.cuda.stream(stream or torch.cuda.current_stream()):
+                            t.mul_(2.0)
+                solver._rccl = SameGradientsOnTheOtherRank()
         ds = model.prepare_samples(samples)
         losses = [float(solver.train_step(ds)[0]) for _ in range(4)]
         out[mode] = (losses, {k: v.clone() for k, v in model.store.state_dict().items()})
@@ -269,8 +278,11 @@ def test_data_parallel_step_structure_on_one_gpu():
             assert any(isinstance(v, _PipelinedGraphStep) for v in solver._graphs.values())
             st = [v for v in solver._graphs.values() if isinstance(v, _PipelinedGraphStep)][0]
             assert st.ranges[0][1] == model.store.n_train and st.ranges[-1][0] == 0
+        if mode == "dp_onegraph":
+            from athena_amd.solver import _OneGraphPipelinedStep
+            assert any(isinstance(v, _OneGraphPipelinedStep) for v in solver._graphs.values())
     os.environ.pop("ATHENA_DP_PIPELINE", None)
-    for mode in ("dp_eager", "dp_graph", "dp_graph_unpipelined"):
+    for mode in ("dp_eager", "dp_graph", "dp_graph_unpipelined", "dp_onegraph"):
         for a, b in zip(out["single"][0], out[mode][0]):
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (mode, out["single"][0], out[mode][0])
         worst = max(rel_err(out[mode][1][k], out["single"][1][k].double().cpu()) for k in out[mode][1]
