@@ -20,6 +20,8 @@
 #define CTC_MAX_R 16            // lattice states per lane: supports 2U+1 <= 1024
 #define CTC_MAX_U (64 * CTC_MAX_R / 2)   // label positions
 #define CTC_EMIS_PAD 16         // rows of padding in front of and behind the emission table
+// the beta rows of the R = 2 lattice are stored shifted by one state (see ctc_lattice_kernel)
+#define CTC_BETA_SHIFT(R) ((R) == 2)
 #define CTC_LOG2E 1.4426950408889634f
 #define CTC_LN2 0.6931471805599453
 
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
     __shared__ int32_t labs[CTC_MAX_U];
     const int row = blockIdx.x;
     const int b = row / T_, t = row - b * T_;
+    if (row == 0 && threadIdx.x == 0) emis[-1] = 0.0;      // read (and multiplied by zero) by the shifted beta recursion
     if (t == 0) {
         // labels that repeat share one logits column: ctc_post sums their occupancies at the first of them
         for (int u = threadIdx.x; u < U; u += 256) labs[u] = labels[(long)b * U + u];
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
     constexpr int HR = R / 2;                   // labels per lane = doubles per lane in an emission row
     constexpr int Lp = Sp / 2;
     constexpr bool kParity = true;
+    constexpr bool kBetaShift = CTC_BETA_SHIFT(R);
     // emission rows fetched ahead of the recursion through a ring of registers; one trip of the
     // unrolled loop is one turn of that ring
     constexpr int PF = R <= 4 ? 16 : (R <= 12 ? 8 : 4);
@@ -968,6 +972,30 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
         // ---------------- beta: vector i is time len-1-i.  beta[len-1][s] = 1 for final states;
         // beta[t][s] = sum over successors s' in {s, s+1, s+2(skip)} of beta[t+1][s'] * p[t+1][s'],
         // so step i reads the emissions of time len-i
+        if constexpr (kBetaShift) {
+            // R = 2: the lane holds (label 2l-1, blank 2l) instead of (blank 2l, label 2l+1), the mirror
+            // image of what the alpha recursion has: both successors of a state that are not in its own
+            // lane are then the label state of the next lane -- one neighbour exchange per step, not two.
+            // Vector entry j of a stored beta row therefore belongs to state j - 1 (ctc_post knows).
+            // Lane 0's label slot is the state "-1": nothing reads it, and its emission is the last
+            // entry of the table row in front (always 0 with at most 63 labels in 64 entries; in front
+            // of the first row the padding entry that ctc_row_kernel zeroes).
+            const double skip_l = (lane >= 1 && 2 * lane + 1 < Sb && lab_c[0] != lab_p[0]) ? 1.0 : 0.0;
+            auto step = [&](const double (&p)[HR], int ph) {
+                const double w0 = a[0] * p[0];
+                const double n0 = lane_next_f64(w0);
+                a[0] = fma(n0, skip_l, w0 + a[1]);
+                a[1] = a[1] + n0;
+                if (ph == 0) rescale();
+            };
+            // final states: blank 2L = slot 1 of lane L, label 2L-1 = slot 0 of lane L
+            a[0] = (lane == L && L >= 1) ? 1.0 : 0.0;
+            a[1] = lane == L ? 1.0 : 0.0;
+            put(DS - 1, a);
+            if (len == 1) lds_poke(&prod[dir], 1);
+            ep = eb - 1 + (long)(len - 1) * Lp;
+            trips(step, -Lp);
+        } else {
         auto step = [&](const double (&p)[HR], int ph) {
             double w[R];
 #pragma unroll
@@ -996,6 +1024,7 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
         if (len == 1) lds_poke(&prod[dir], 1);
         ep = eb + (long)(len - 1) * Lp;
         trips(step, -Lp);
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     }
@@ -1049,7 +1078,7 @@ __global__ __launch_bounds__(256) void ctc_post_kernel(const int32_t* __restrict
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         av[i] = ar[lane + 64 * i];
-        bv[i] = br[lane + 64 * i];
+        bv[i] = br[lane + 64 * i + (CTC_BETA_SHIFT(R) ? 1 : 0)];
     }
     if (grad != nullptr && U > 0) {
         const int32_t* lab = labels + (long)b * U;
