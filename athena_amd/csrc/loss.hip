@@ -298,6 +298,22 @@ __device__ __forceinline__ int wave_imax_dpp(int v) {
     const int r3 = __builtin_amdgcn_readlane(v, 48);
     return max(max(r0, r1), max(r2, r3));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_fadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over the wave, the same way
+__device__ __forceinline__ float wave_fsum_dpp(float v) {
+    v = dpp_fadd<0xB1>(v);
+    v = dpp_fadd<0x4E>(v);
+    v = dpp_fadd<0x141>(v);
+    v = dpp_fadd<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 // The high words of non-negative doubles order like the doubles.  From the largest high word of a
 // set: the power of two that brings its owner into [1, 2) (0 if the set is all zero or not finite).
 __device__ __forceinline__ int scale_exponent(int max_hi) {
@@ -491,6 +507,22 @@ __device__ __forceinline__ double lse_pair(double a, double b) {
 // sample's part of the alpha buffer, writes the posterior list of all U labels (and, with ``grad``,
 // the gradient columns that have an occupancy) from the backward loop and raises flags[b], which
 // tells ctc_grad to scatter all U + 1 entries.
+// reductions over the first four waves of a workgroup (the slow path runs on those, whatever the
+// size of the workgroup it is called from); ``red``: 4 floats of LDS; every thread gets the result
+__device__ __forceinline__ float slow_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float slow_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 struct CtcSlowLds {
     double st[2][64 * CTC_MAX_R];
     float red[32];
@@ -565,7 +597,7 @@ __device__ __forceinline__ void ctc_slow_path(CtcSlowLds& lds, int b, const T* _
                 mx = fmaxf(mx, (float)nv[i]);
             }
         }
-        mx = block_max(mx, red);
+        mx = slow_max(mx, red);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int s = tid + 256 * i;
@@ -604,14 +636,14 @@ __device__ __forceinline__ void ctc_slow_path(CtcSlowLds& lds, int b, const T* _
                     pm = fmaxf(pm, pv[i]);
                 }
             }
-            pm = block_max(pm, red);
+            pm = slow_max(pm, red);
             float ps = 0.f;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 pv[i] = (tid + 256 * i < S2) ? __builtin_amdgcn_exp2f(pv[i] - pm) : 0.f;
                 ps += pv[i];
             }
-            ps = block_sum(ps, red);
+            ps = slow_sum(ps, red);
             const float inv = ps > 0.f ? 1.f / ps : 0.f;
             float* orow = occ + ((long)b * T_ + t) * Up;
             if (grad) {
@@ -635,7 +667,7 @@ __device__ __forceinline__ void ctc_slow_path(CtcSlowLds& lds, int b, const T* _
                     }
                 }
             }
-            bl = block_sum(bl, red);
+            bl = slow_sum(bl, red);
             if (tid == 0) orow[0] = bl;
             if (grad) {
                 const T* lr = lb + (long)t * ldl;
@@ -674,7 +706,7 @@ __device__ __forceinline__ void ctc_slow_path(CtcSlowLds& lds, int b, const T* _
         double ns = st[cur ^ 1][0];                          // start -> blank 0
         if (S2 > 1) ns = lse_pair(ns, st[cur ^ 1][1]);       // start -> label 1
         mx = fmaxf(mx, (float)ns);
-        mx = block_max(mx, red);                             // (its barriers also end the reads of w)
+        mx = slow_max(mx, red);                             // (its barriers also end the reads of w)
         cum += (double)mx;
         bstart = ns - (double)mx;
 #pragma unroll
@@ -727,6 +759,135 @@ __device__ __forceinline__ void load_states(const double* __restrict__ src, doub
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) e[r] = src[r];
+    }
+}
+
+// The posterior of one logits row from its two lattice rows, by one wave: lane l holds the states
+// l, l + 64, ... (a state and its lane have the same parity: even lanes hold blank states, odd lanes
+// labels; states beyond the sample's last one hold zeros).  alpha * beta normalised (the power-of-two
+// scales of the two factors are constants of the row and cancel) leaves as a short list --
+// occ[row][0] = all blank states together, occ[row][1 + u] = the state of label u -- and, with
+// ``grad``, the gradient columns of the row that have an occupancy are written again, complete.
+// ``totw``: Lp floats of LDS that belong to the wave.
+template <typename TG, int R>
+__device__ __forceinline__ void ctc_post_row(long row, int lane, int Sb, int V, int blank, int ldl, int Up, bool fix,
+                                             const double (&av)[R], const double (&bv)[R], const double (&pe)[R],
+                                             const int (&cl)[R], const int (&fu)[R], float nr, float* totw,
+                                             float* __restrict__ occ, float gscale, TG* __restrict__ grad) {
+    int mh = 0;
+    double w[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        w[i] = lane + 64 * i < Sb ? av[i] * bv[i] : 0.0;
+        mh = max(mh, __double2hiint(w[i]));
+    }
+    const int k = scale_exponent(wave_imax_dpp(mh));
+    float f[R];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        f[i] = (float)ldexp(w[i], -k);
+        sm += f[i];
+    }
+    float* orow = occ + row * Up;
+    // Labels that repeat (their occupancies are summed at the first of them) or that name the blank
+    // class need the sums in LDS below.  Without any -- the usual sample -- the blank column gets what
+    // the even lanes hold and every label state its own column: one reduction that keeps the two
+    // parities of the lanes apart (lanes l ^ 2, then the row of 16 lanes rotated by 4 and by 8) gives
+    // both the normaliser and the blank sum.
+    bool plain = true;
+    if (fix) {
+        bool odd_one = false;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int s = lane + 64 * i;
+            odd_one = odd_one || ((s & 1) && s < Sb && fu[i] != (s >> 1));
+        }
+        plain = !__any(odd_one);
+    }
+    if (plain) {
+        float e = sm;
+        e = dpp_fadd<0x4E>(e);      // quad_perm [2,3,0,1]
+        e = dpp_fadd<0x124>(e);     // row_ror:4
+        e = dpp_fadd<0x128>(e);     // row_ror:8
+        float part[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            part[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e), 16 * (q >> 1) + (q & 1)));
+        const float even = (part[0] + part[2]) + (part[4] + part[6]);
+        const float odd = (part[1] + part[3]) + (part[5] + part[7]);
+        const float tot = even + odd;
+        const float inv = tot > 0.f ? __builtin_amdgcn_rcpf(tot) : 0.f;
+        const float bl = even * inv;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int s = lane + 64 * i;
+            f[i] *= inv;
+            if ((s & 1) && s < Sb) orow[1 + (s >> 1)] = f[i];
+        }
+        if (lane == 0) orow[0] = bl;
+        if (grad) {
+            TG* gr = grad + row * ldl;
+            const double pb = (double)__expf(-nr);
+            if (fix) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    const int s = lane + 64 * i;
+                    if ((s & 1) && s < Sb && cl[i] >= 0 && cl[i] < V)
+                        ctc_store1<TG>(gr + cl[i], gscale * ((float)(pe[i] * pb) - f[i]));
+                }
+            }
+            if (lane == 0) ctc_store1<TG>(gr + blank, gscale * ((float)pb - bl));
+        }
+        return;
+    }
+    sm = wave_fsum_dpp(sm);
+    const float inv = sm > 0.f ? __builtin_amdgcn_rcpf(sm) : 0.f;
+    float bl = 0.f;
+    if (fix) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int s = lane + 64 * i;
+            if ((s & 1) && s < Sb) totw[s >> 1] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int s = lane + 64 * i;
+        f[i] *= inv;
+        if (s < Sb) {
+            if (s & 1) {
+                orow[1 + (s >> 1)] = f[i];
+                if (fix) {
+                    if (fu[i] < 0) bl += f[i];
+                    else atomicAdd(&totw[fu[i]], f[i]);
+                }
+            } else {
+                bl += f[i];
+            }
+        }
+    }
+    bl = wave_fsum_dpp(bl);
+    if (lane == 0) orow[0] = bl;
+    if (grad) {
+        // The row launch left gscale * softmax in the row.  softmax of a label's column = its emission
+        // (relative to blank) times the softmax of the blank column, exp(-(lse - logit[blank])).
+        // The sums in LDS were made by this wave: LDS operations are carried out in the order they
+        // were issued, so the wave only has to wait for its own (a fence would also wait for the
+        // stores above to be acknowledged).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TG* gr = grad + row * ldl;
+        const double pb = (double)__expf(-nr);
+        if (fix) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const int s = lane + 64 * i;
+                if ((s & 1) && s < Sb && fu[i] == (s >> 1) && cl[i] >= 0 && cl[i] < V)
+                    ctc_store1<TG>(gr + cl[i], gscale * ((float)(pe[i] * pb) - totw[s >> 1]));
+            }
+        }
+        if (lane == 0) ctc_store1<TG>(gr + blank, gscale * ((float)pb - bl));
+        asm volatile("" ::: "memory");
     }
 }
 
@@ -1044,9 +1205,10 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
 //
 // With ``grad`` the wave also writes the gradient columns of its row that have an occupancy.  Samples
 // the lattice launch found no path for are its slow path's business and skipped here.
-#define CTC_POST_ROWS 4
+// (16 rows = 16 waves where the kernel fits 128 registers per lane, 8 otherwise)
+#define CTC_POST_ROWS(R) ((R) <= 4 ? 16 : 8)
 template <typename TG, int R>
-__global__ __launch_bounds__(256) void ctc_post_kernel(const int32_t* __restrict__ labels,
+__global__ __launch_bounds__(64 * CTC_POST_ROWS(R)) void ctc_post_kernel(const int32_t* __restrict__ labels,
                                                        const int32_t* __restrict__ label_len,
                                                        const int32_t* __restrict__ logit_len, int T_, int V,
                                                        int U, int blank, int ldl, int Up, int chunks,
@@ -1059,10 +1221,10 @@ __global__ __launch_bounds__(256) void ctc_post_kernel(const int32_t* __restrict
                                                        int32_t* __restrict__ flags, float* __restrict__ loss,
                                                        float gscale, TG* __restrict__ grad) {
     constexpr int Sp = 64 * R, Lp = Sp / 2;
-    __shared__ float tot[CTC_POST_ROWS][Lp];     // occupancy by label position, one set per wave
+    __shared__ float tot[CTC_POST_ROWS(R)][Lp];     // occupancy by label position, one set per wave
     const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t = chunk * CTC_POST_ROWS + wv;
+    const int t = chunk * CTC_POST_ROWS(R) + wv;
     const long row = (long)b * T_ + min(t, T_ - 1);
     // Everything the row needs is requested at once, before anything is tested (a load that waited
     // for the lengths, and the lengths for each other, would cost a memory latency each): lane l
@@ -1115,69 +1277,7 @@ __global__ __launch_bounds__(256) void ctc_post_kernel(const int32_t* __restrict
     if (t >= len) return;
     const int Sb = 2 * L + 1;
     const bool fix = grad != nullptr && L > 0;   // (wave-uniform)
-    int mh = 0;
-    double w[R];
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        w[i] = lane + 64 * i < Sb ? av[i] * bv[i] : 0.0;
-        mh = max(mh, __double2hiint(w[i]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mh = max(mh, __shfl_xor(mh, o, 64));
-    const int k = scale_exponent(mh);
-    float f[R];
-    float sm = 0.f;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        f[i] = (float)ldexp(w[i], -k);
-        sm += f[i];
-    }
-    sm = wave_sum(sm);
-    const float inv = sm > 0.f ? 1.f / sm : 0.f;
-    float* orow = occ + row * Up;
-    float bl = 0.f;
-    if (fix) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int s = lane + 64 * i;
-            if ((s & 1) && s < Sb) tot[wv][s >> 1] = 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int s = lane + 64 * i;
-        f[i] *= inv;
-        if (s < Sb) {
-            if (s & 1) {
-                orow[1 + (s >> 1)] = f[i];
-                if (fix) {
-                    if (fu[i] < 0) bl += f[i];
-                    else atomicAdd(&tot[wv][fu[i]], f[i]);
-                }
-            } else {
-                bl += f[i];
-            }
-        }
-    }
-    bl = wave_sum(bl);
-    if (lane == 0) orow[0] = bl;
-    if (grad) {
-        // The row launch left gscale * softmax in the row: the columns with an occupancy are written
-        // again, complete.  softmax of a label's column = its emission (relative to blank) times the
-        // softmax of the blank column, exp(-(lse - logit[blank])).
-        __threadfence_block();
-        TG* gr = grad + row * ldl;
-        const double pb = (double)__expf(-nr);
-        if (fix) {
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int s = lane + 64 * i;
-                if ((s & 1) && s < Sb && fu[i] == (s >> 1) && cl[i] >= 0 && cl[i] < V)
-                    ctc_store1<TG>(gr + cl[i], gscale * ((float)(pe[i] * pb) - tot[wv][s >> 1]));
-            }
-        }
-        if (lane == 0) ctc_store1<TG>(gr + blank, gscale * ((float)pb - bl));
-    }
+    ctc_post_row<TG, R>(row, lane, Sb, V, blank, ldl, Up, fix, av, bv, pe, cl, fu, nr, tot[wv], occ, gscale, grad);
 }
 
 // ---------------------------------------------------------------- ctc_grad
@@ -1288,13 +1388,12 @@ static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, 
         hipLaunchKernelGGL((ctc_row_kernel<T, TG, false>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels,
                            label_len, logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first,
                            gscale, grad);
-    const int chunks = (Tn + CTC_POST_ROWS - 1) / CTC_POST_ROWS;
 #define CTC_LAT_POST(N)                                                                                          \
     hipLaunchKernelGGL((ctc_lattice_kernel<T, TG, N>), dim3(B), dim3(256), 0, s, ws.emis, labels, label_len,     \
                        logit_len, Tn, U, ws.alpha, ws.beta, ws.ll, logits, ldl, V, blank, ws.Up, ws.lse, ws.occ, \
                        ws.first, ws.flags, loss, gscale, grad);                                                  \
-    hipLaunchKernelGGL((ctc_post_kernel<TG, N>), dim3(B * chunks), dim3(256), 0, s, labels, label_len, logit_len, \
-                       Tn, V, U, blank, ldl, ws.Up, chunks, ws.nrm, ws.emis, ws.alpha, ws.beta, ws.occ, ws.first, \
+    hipLaunchKernelGGL((ctc_post_kernel<TG, N>), dim3(B * ((Tn + CTC_POST_ROWS(N) - 1) / CTC_POST_ROWS(N))), dim3(64 * CTC_POST_ROWS(N)), 0, s, labels, label_len, logit_len, \
+                       Tn, V, U, blank, ldl, ws.Up, (Tn + CTC_POST_ROWS(N) - 1) / CTC_POST_ROWS(N), ws.nrm, ws.emis, ws.alpha, ws.beta, ws.occ, ws.first, \
                        ws.ll, ws.flags, loss, gscale, grad)
     switch (ctc_launch_r(2 * U + 1)) {
         case 2: CTC_LAT_POST(2); break;
