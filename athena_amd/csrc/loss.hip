@@ -190,6 +190,38 @@ __device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V
     m_out = gm;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_fadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum / maximum over the wave: four DPP steps inside each row of 16 lanes (quad swaps, half mirror,
+// mirror), then the four row results through scalar registers -- no trip through the LDS crossbar
+__device__ __forceinline__ float wave_fsum_dpp(float v) {
+    v = dpp_fadd<0xB1>(v);
+    v = dpp_fadd<0x4E>(v);
+    v = dpp_fadd<0x141>(v);
+    v = dpp_fadd<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_fmax(float v) {
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float wave_fmax_dpp(float v) {
+    v = dpp_fmax<0xB1>(v);
+    v = dpp_fmax<0x4E>(v);
+    v = dpp_fmax<0x141>(v);
+    v = dpp_fmax<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 // fp32 rows of at most CTC_ROW_REGS * 1024 columns with ld % 4 == 0: the whole row is fetched into
 // registers before anything depends on it (all loads of a thread in flight at once instead of one
 // per trip of an online loop), then maximum, first arg-max and the sum of exponentials relative to
@@ -197,9 +229,10 @@ __device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V
 // V .. ld-1 are padding and come back as -inf).  Two workgroup reductions: the maximum, then the
 // sum and the arg-max candidates together.
 #define CTC_ROW_REGS 8
-__device__ __forceinline__ void row_regs_load(const float* __restrict__ row, int ld, float4 (&x)[CTC_ROW_REGS]) {
+template <int NR>
+__device__ __forceinline__ void row_regs_load(const float* __restrict__ row, int ld, float4 (&x)[NR]) {
 #pragma unroll
-    for (int i = 0; i < CTC_ROW_REGS; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int c = (i * 256 + threadIdx.x) * 4;
         x[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         if (c < ld) x[i] = *(const float4*)(row + c);
@@ -209,12 +242,16 @@ __device__ __forceinline__ void row_regs_load(const float* __restrict__ row, int
 // by lane shuffles (maximum, first column holding it, sum of exponentials relative to the wave's
 // maximum), lane 0 of each wave leaves the three numbers in LDS, and behind the barrier every thread
 // combines the four waves' numbers for itself.  ``slot``: 12 floats of LDS.
-__device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V, float& m_out, float& s_out,
-                                               int& arg_out, float* slot) {
+// kKeep: the registers come back holding exp(x - the wave's maximum), the exponentials the sum was
+// made of, and ``w_out`` the factor exp(wave maximum - row maximum) that turns them into
+// exp(x - row maximum): a caller that goes on to write the softmax needs no second exponential.
+template <bool kKeep, int NR>
+__device__ __forceinline__ void row_regs_stats(float4 (&x)[NR], int V, float& m_out, float& s_out,
+                                               int& arg_out, float* slot, float& w_out) {
     float m = -INFINITY;
     int idx = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < CTC_ROW_REGS; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int c = (i * 256 + threadIdx.x) * 4;
         if (c + 3 >= V) {
             if (c + 0 >= V) x[i].x = -INFINITY;
@@ -228,16 +265,27 @@ __device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V,
             idx = c + (x[i].x == mx ? 0 : x[i].y == mx ? 1 : x[i].z == mx ? 2 : 3);
         }
     }
-    const float wm = wave_max(m);
+    const float wm = wave_fmax_dpp(m);
     float s = 0.f;
     if (wm != -INFINITY) {
+        const float nwm = -wm * CTC_LOG2E;
 #pragma unroll
-        for (int i = 0; i < CTC_ROW_REGS; ++i)
-            s += __expf(x[i].x - wm) + __expf(x[i].y - wm) + __expf(x[i].z - wm) + __expf(x[i].w - wm);
+        for (int i = 0; i < NR; ++i) {
+            // exp(x - wm) = 2^(x log2(e) - wm log2(e)): one multiply-add and the exponential unit
+            const float4 e = make_float4(__builtin_amdgcn_exp2f(fmaf(x[i].x, CTC_LOG2E, nwm)),
+                                         __builtin_amdgcn_exp2f(fmaf(x[i].y, CTC_LOG2E, nwm)),
+                                         __builtin_amdgcn_exp2f(fmaf(x[i].z, CTC_LOG2E, nwm)),
+                                         __builtin_amdgcn_exp2f(fmaf(x[i].w, CTC_LOG2E, nwm)));
+            s += (e.x + e.y) + (e.z + e.w);
+            if constexpr (kKeep) x[i] = e;
+        }
+    } else if constexpr (kKeep) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    s = wave_sum(s);
+    s = wave_fsum_dpp(s);
     // smallest column among the lanes that saw the wave's maximum (column indices are exact in fp32)
-    const float cand = wave_max(m == wm && idx != 0x7fffffff ? -(float)idx : -INFINITY);
+    const float cand = wave_fmax_dpp(m == wm && idx != 0x7fffffff ? -(float)idx : -INFINITY);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
         slot[w] = wm;
@@ -256,6 +304,7 @@ __device__ __forceinline__ void row_regs_stats(float4 (&x)[CTC_ROW_REGS], int V,
     m_out = gm;
     s_out = tot;
     arg_out = best == -INFINITY ? 0 : (int)(-best);
+    w_out = wm != -INFINITY ? __expf(wm - gm) : 0.f;
 }
 
 // ---------------------------------------------------------------- lattice arithmetic
@@ -297,22 +346,6 @@ __device__ __forceinline__ int wave_imax_dpp(int v) {
     const int r2 = __builtin_amdgcn_readlane(v, 32);
     const int r3 = __builtin_amdgcn_readlane(v, 48);
     return max(max(r0, r1), max(r2, r3));
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_fadd(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-// sum over the wave, the same way
-__device__ __forceinline__ float wave_fsum_dpp(float v) {
-    v = dpp_fadd<0xB1>(v);
-    v = dpp_fadd<0x4E>(v);
-    v = dpp_fadd<0x141>(v);
-    v = dpp_fadd<0x140>(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (r0 + r1) + (r2 + r3);
 }
 // The high words of non-negative doubles order like the doubles.  From the largest high word of a
 // set: the power of two that brings its owner into [1, 2) (0 if the set is all zero or not finite).
@@ -377,7 +410,10 @@ __device__ __forceinline__ void ctc_store1(TG* p, float a) { *p = (TG)a; }
 //   * kGrad: the dense part of the gradient, gscale * softmax(row), written while the row is in
 //     registers (the padding columns and the rows beyond logit_length as zeros); ctc_post subtracts
 //     the occupancy at the few columns that have one
-template <typename T, typename TG, bool kGrad>
+//   NR: fp32 rows of up to NR * 1024 columns are held in registers (four columns per thread and
+//       register set); the launch picks the smallest of the sizes built that fits the row, since the
+//       statistics and the softmax are worked out for every register set whether the row reaches it or not
+template <typename T, typename TG, bool kGrad, int NR>
 __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logits, int ldl,
                                                       const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ label_len,
@@ -412,10 +448,10 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
     }
     const T* lr = logits + (long)row * ldl;
     bool in_regs = false;
-    if constexpr (sizeof(T) == 4) in_regs = ldl <= CTC_ROW_REGS * 1024;
-    float4 x[CTC_ROW_REGS];
+    if constexpr (sizeof(T) == 4) in_regs = ldl <= NR * 1024;
+    float4 x[NR];
     if constexpr (sizeof(T) == 4) {
-        if (in_regs) row_regs_load((const float*)lr, ldl, x);
+        if (in_regs) row_regs_load<NR>((const float*)lr, ldl, x);
     }
     // the emissions are requested behind the row, so they arrive during its reductions
     const int L = min(max(label_len[b], 0), U);
@@ -433,10 +469,10 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
         }
     }
     const float xb = to_f32<T>(lr[blank]);
-    float m, sum;
+    float m, sum, wfac = 0.f;
     int am = 0;
     if (in_regs) {
-        if constexpr (sizeof(T) == 4) row_regs_stats(x, V, m, sum, am, red);
+        if constexpr (sizeof(T) == 4) row_regs_stats<kGrad, NR>(x, V, m, sum, am, red, wfac);
     } else if (argmax) {
         row_max_sum_arg<T>(lr, V, m, sum, am, red);
     } else {
@@ -462,13 +498,12 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
         TG* gr = grad + (long)row * ldl;
         if (in_regs) {
             if constexpr (sizeof(T) == 4) {
+                const float gfac = sum > 0.f ? gscale * wfac / sum : 0.f;
 #pragma unroll
-                for (int i = 0; i < CTC_ROW_REGS; ++i) {
+                for (int i = 0; i < NR; ++i) {
                     const int c = (i * 256 + threadIdx.x) * 4;
-                    // masked columns hold -inf: their exponential is the zero the padding wants
-                    if (c < ldl)
-                        ctc_store4<TG>(gr + c, gscale * __expf(x[i].x - l), gscale * __expf(x[i].y - l),
-                                       gscale * __expf(x[i].z - l), gscale * __expf(x[i].w - l));
+                    // the registers hold exp(x - wave maximum) (masked columns the zero the padding wants)
+                    if (c < ldl) ctc_store4<TG>(gr + c, gfac * x[i].x, gfac * x[i].y, gfac * x[i].z, gfac * x[i].w);
                 }
             }
         } else {
@@ -1380,14 +1415,17 @@ template <typename T, typename TG>
 static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
                                const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
                                float* loss, int32_t* argmax, float gscale, TG* grad, hipStream_t s) {
-    if (grad)
-        hipLaunchKernelGGL((ctc_row_kernel<T, TG, true>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels,
-                           label_len, logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first,
-                           gscale, grad);
-    else
-        hipLaunchKernelGGL((ctc_row_kernel<T, TG, false>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels,
-                           label_len, logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first,
-                           gscale, grad);
+#define CTC_ROW(G, NR)                                                                                         \
+    hipLaunchKernelGGL((ctc_row_kernel<T, TG, G, NR>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len, \
+                       logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first, gscale, grad)
+    if (grad) {
+        if (ldl <= 5 * 1024) CTC_ROW(true, 5);
+        else CTC_ROW(true, CTC_ROW_REGS);
+    } else {
+        if (ldl <= 5 * 1024) CTC_ROW(false, 5);
+        else CTC_ROW(false, CTC_ROW_REGS);
+    }
+#undef CTC_ROW
 #define CTC_LAT_POST(N)                                                                                          \
     hipLaunchKernelGGL((ctc_lattice_kernel<T, TG, N>), dim3(B), dim3(256), 0, s, ws.emis, labels, label_len,     \
                        logit_len, Tn, U, ws.alpha, ws.beta, ws.ll, logits, ldl, V, blank, ws.Up, ws.lse, ws.occ, \
