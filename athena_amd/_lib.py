@@ -159,6 +159,7 @@ _SIGNATURES = {
     "athena_refresh_shadows": (c_int, [_P, _P, _P, c_int, _P, c_long, _S]),
     "athena_advance_rng": (c_int, [_P, _S]),
     "athena_cast": (c_int, [_P, c_int, _P, c_int, c_long, _S]),
+    "athena_copy_many": (c_int, [_P, _P, _P, c_int, _S]),
     "athena_axpby": (c_int, [c_float, _P, c_float, _P, c_long, c_int, _S]),
 }
 

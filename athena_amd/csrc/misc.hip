@@ -352,6 +352,53 @@ extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L
     return ATHENA_OK;
 }
 
+// ---------------------------------------------------------------- several copies, one launch
+// A training step starts by copying a handful of small tensors (lengths, labels, the feature batch)
+// into the buffers its recorded graph reads, and ends by copying a handful of small tensors (the
+// arg-max ids of the metrics) to pinned host memory; as separate copies each is a launch of 4 us
+// or more with a host round in between.  blockIdx.y picks the copy, the x blocks stride over it.
+struct CopyMany {
+    const void* src[ATHENA_COPY_MANY_MAX];
+    void* dst[ATHENA_COPY_MANY_MAX];
+    long bytes[ATHENA_COPY_MANY_MAX];
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyMany c) {
+    const int k = blockIdx.y;
+    const char* src = (const char*)c.src[k];
+    char* dst = (char*)c.dst[k];
+    const long n = c.bytes[k];
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, nthr = (long)gridDim.x * 256;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const long n16 = n >> 4;
+        for (long i = tid; i < n16; i += nthr) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        for (long i = (n16 << 4) + tid; i < n; i += nthr) dst[i] = src[i];
+    } else {
+        for (long i = tid; i < n; i += nthr) dst[i] = src[i];
+    }
+}
+
+extern "C" int athena_copy_many(const void* const* src, void* const* dst, const long* bytes, int n,
+                                athena_stream_t stream) {
+    ATHENA_REQUIRE(src && dst && bytes && n > 0 && n <= ATHENA_COPY_MANY_MAX, ATHENA_E_SHAPE,
+                   "athena_copy_many: 1 to %d copies", ATHENA_COPY_MANY_MAX);
+    CopyMany c;
+    long most = 0;
+    for (int i = 0; i < ATHENA_COPY_MANY_MAX; ++i) {
+        const int k = i < n ? i : 0;
+        ATHENA_REQUIRE(src[k] && dst[k] && bytes[k] >= 0, ATHENA_E_SHAPE, "athena_copy_many: bad copy %d", k);
+        c.src[i] = src[k];
+        c.dst[i] = dst[k];
+        c.bytes[i] = i < n ? bytes[k] : 0;
+        if (c.bytes[i] > most) most = c.bytes[i];
+    }
+    long blocks = (most / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, c);
+    ATHENA_CHECK_LAUNCH("athena_copy_many");
+    return ATHENA_OK;
+}
+
 // ---------------------------------------------------------------- casts / axpby
 template <typename TS, typename TD>
 __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n) {

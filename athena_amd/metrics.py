@@ -96,11 +96,17 @@ class _Deferred:
 
     def to_host(self):
         if self.event is None and any(t.is_cuda for t in self.tensors):
-            host = []
+            # all of them in one launch (the pinned buffers are addressable from the device)
+            host, pairs = [], []
             for t in self.tensors:
                 h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                h.copy_(t, non_blocking=True)
+                if t.is_cuda and t.is_contiguous():
+                    pairs.append((t, h))
+                else:
+                    h.copy_(t, non_blocking=True)
                 host.append(h)
+            if pairs:
+                ops.copy_many(pairs)
             self.event = torch.cuda.Event()
             self.event.record()
             self.tensors = host

@@ -889,6 +889,29 @@ def cast(src, dst):
                "athena_cast")
 
 
+COPY_MANY_MAX = 8
+
+
+def copy_many(pairs):
+    """``dst.copy_(src)`` for every (src, dst) of ``pairs`` -- contiguous tensors of equal dtype and
+    size, each on the device or in pinned host memory -- as one launch per eight pairs."""
+    import ctypes
+    pairs = [(s, d) for s, d in pairs if s.numel() > 0]
+    for s, d in pairs:
+        if s.dtype != d.dtype or s.numel() != d.numel() or not s.is_contiguous() or not d.is_contiguous():
+            raise RuntimeError("athena_amd.copy_many: tensors of a pair must be contiguous and alike")
+        if not (s.is_cuda or s.is_pinned()) or not (d.is_cuda or d.is_pinned()):
+            raise RuntimeError("athena_amd.copy_many: device or pinned host tensors only")
+    lib = _lib.load()
+    for i in range(0, len(pairs), COPY_MANY_MAX):
+        part = pairs[i:i + COPY_MANY_MAX]
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[s.data_ptr() for s, _ in part])
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for _, d in part])
+        nbytes = (ctypes.c_long * n)(*[s.numel() * s.element_size() for s, _ in part])
+        _lib.check(lib.athena_copy_many(src, dst, nbytes, n, _stream()), "athena_copy_many")
+
+
 # ------------------------------------------------------------------------------------------ bf16 gradient hand-over
 # autograd casts a gradient to the dtype of the tensor it belongs to, so a loss kernel cannot hand a
 # bf16 gradient for fp32 logits back through it.  Inside a solver step (``bf16_grad_handover``), when

@@ -211,6 +211,21 @@ def _capture(graph, pool):
             gc.enable()
 
 
+def _copy_inputs(buffers, samples):
+    """The batch into the buffers a recorded step reads: device tensors as one launch, anything else
+    (a host batch) by the runtime's copies."""
+    pairs = []
+    for k, v in buffers.items():
+        src = samples[k]
+        if src.is_cuda and v.is_cuda and src.dtype == v.dtype and src.shape == v.shape and src.is_contiguous():
+            if src.data_ptr() != v.data_ptr():
+                pairs.append((src, v))
+        else:
+            v.copy_(src, non_blocking=True)
+    if pairs:
+        ops.copy_many(pairs)
+
+
 def _shape_key(samples):
     return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(samples.items()))
 
@@ -252,8 +267,7 @@ class _GraphStep:
 
     def run(self, samples):
         from .metrics import _Deferred
-        for k, v in self.inputs.items():
-            v.copy_(samples[k], non_blocking=True)
+        _copy_inputs(self.inputs, samples)
         self.graph.replay()
         if self.update_graph is not None:
             self.solver._reduce_gradients()
@@ -326,8 +340,7 @@ class _PipelinedGraphStep:
 
     def run(self, samples):
         from .metrics import _Deferred
-        for k, v in self.inputs.items():
-            v.copy_(samples[k], non_blocking=True)
+        _copy_inputs(self.inputs, samples)
         grads = self.solver.model.store.grads
         step = max(int(self.solver.BUCKET_MB * (1 << 20) / 4), 1)
         works = []
@@ -408,8 +421,7 @@ class _OneGraphPipelinedStep:
 
     def run(self, samples):
         from .metrics import _Deferred
-        for k, v in self.inputs.items():
-            v.copy_(samples[k], non_blocking=True)
+        _copy_inputs(self.inputs, samples)
         self.graph.replay()
         self.solver.model.store.shadows_dirty = True
         for m, items in self.templates:

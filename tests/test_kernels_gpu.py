@@ -1051,3 +1051,23 @@ def test_prepare_labels_matches_reference_helpers(ops):
     assert torch.equal(got[2].cpu(), (y0 == 0).to(torch.uint8))
     assert torch.equal(got[3].cpu(), tl)
     assert torch.equal(got[4].cpu(), xm)
+
+
+def test_copy_many_device_and_pinned(ops):
+    """Several copies in one launch: device to device (aligned and not), device to pinned host
+    memory, more pairs than one launch takes, an empty tensor."""
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(n, generator=g).to(dev()) for n in (1, 7, 1024, 100003, 33, 5, 64, 129, 4097, 2)]
+    srcs.append(torch.randint(0, 100, (32, 17), generator=g, dtype=torch.int32).to(dev()))
+    srcs.append(torch.empty(0, device=dev()))
+    odd = torch.randn(1000, generator=g).to(dev())[3:900]          # not 16-byte aligned
+    srcs.append(odd.contiguous()[1:])
+    dsts = [torch.zeros_like(s) for s in srcs]
+    pinned = torch.zeros(4097, pin_memory=True)
+    dsts[8] = pinned
+    ops.copy_many(list(zip(srcs, dsts)))
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s.cpu(), d.cpu())
+    with pytest.raises(RuntimeError):
+        ops.copy_many([(srcs[0], torch.zeros(2, device=dev()))])
