@@ -58,10 +58,11 @@ static int gemm_validate(const athena_gemm_desc* d) {
     const int b_cols = d->trans_b ? d->K : d->N;
     ATHENA_REQUIRE(d->lda >= a_cols && d->ldb >= b_cols && d->ldc >= d->N, ATHENA_E_SHAPE,
                    "athena_gemm: leading dimension too small (lda=%d ldb=%d ldc=%d)", d->lda, d->ldb, d->ldc);
+    // a bf16 output can only be split through the workspace (the second pass converts): automatic split only
     if (d->split_k != 1)
-        ATHENA_REQUIRE(d->out_dtype == ATHENA_F32 && d->act == ATHENA_ACT_NONE && !d->bias && !d->C_pre &&
-                           d->drop_p == 0.f && !d->accumulate,
-                       ATHENA_E_UNSUPPORTED, "athena_gemm: split_k needs a plain fp32 output");
+        ATHENA_REQUIRE((d->out_dtype == ATHENA_F32 || d->split_k == 0) && d->act == ATHENA_ACT_NONE && !d->bias &&
+                           !d->C_pre && d->drop_p == 0.f && !d->accumulate,
+                       ATHENA_E_UNSUPPORTED, "athena_gemm: split_k needs a plain output (fp32, or bf16 with split_k = 0)");
     if (d->act == ATHENA_ACT_MUL_DGELU || d->act == ATHENA_ACT_MUL_DRELU6)
         ATHENA_REQUIRE(d->aux && d->ldaux >= d->N, ATHENA_E_SHAPE, "athena_gemm: backward epilogue needs aux");
     if (d->drop_p > 0.f)
@@ -120,13 +121,14 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     int rc = gemm_validate(d);
     if (rc) return rc;
     const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->in_dtype, 1, d->split_k == 0);
-    const int split = d->split_k == 0 ? plan.split : d->split_k;
+    int split = d->split_k == 0 ? plan.split : d->split_k;
     if (d->b_colsum && d->in_dtype != ATHENA_BF16) {
         rc = athena_colsum(d->B, d->in_dtype, d->K, d->N, d->ldb, d->b_colsum, stream);
         if (rc) return rc;
     }
-    const bool use_ws = d->split_k == 0 && split > 1 && d->workspace && athena_aligned16(d->workspace) &&
-                        (size_t)d->workspace_bytes >= splitk_workspace_bytes(d->M, d->N, split, 1);
+    bool use_ws = d->split_k == 0 && split > 1 && d->workspace && athena_aligned16(d->workspace) &&
+                  (size_t)d->workspace_bytes >= splitk_workspace_bytes(d->M, d->N, split, 1);
+    if (d->out_dtype != ATHENA_F32 && split > 1 && !use_ws) split = 1;      // no atomics onto a bf16 output
     GemmProblem<PlainRows> p;
     gemm_fill(d, split, use_ws ? (float*)d->workspace : nullptr, p);
     if (d->split_k == 0 && split > 1 && !use_ws) {
@@ -147,7 +149,7 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
         const long work = (long)(d->M + 1) * (p.epi.ldp / 4);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, d->M, d->N, p.epi.ldp, (float*)d->C, d->ldc, 0L, d->alpha,
-                           p.epi.bsum);
+                           p.epi.bsum, d->out_dtype == ATHENA_BF16 ? 1 : 0);
         ATHENA_CHECK_LAUNCH("athena_gemm(split-k reduce)");
     }
     return ATHENA_OK;

@@ -945,11 +945,12 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
 
 // Second pass of a split-K product whose workgroups wrote raw partial sums: adds the ``split``
 // slabs of each batch in a fixed order (bit-reproducible, no atomics, no zero-fill of C) and
-// writes C = alpha * sum.  Row M of a slab carries the column sums of B and goes to ``bsum``.
+// writes C = alpha * sum (fp32, or bf16 with ``c_bf16``).  Row M of a slab carries the column sums of
+// B and goes to ``bsum``.
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split, int M, int N,
                                                             int ldp, float* __restrict__ C, int ldc,
                                                             long c_batch_stride, float alpha,
-                                                            float* __restrict__ bsum) {
+                                                            float* __restrict__ bsum, int c_bf16 = 0) {
     // workgroup = 64 column quads x 4 waves; wave w adds slabs w, w + 4, ... and the four partial
     // sums meet in LDS (fixed order: the result does not depend on scheduling)
     __shared__ float4 red[4][64];
@@ -984,6 +985,18 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (n + r < N) bsum[n + r] = v[r];
+        return;
+    }
+    if (c_bf16) {
+        bf16_t* c = (bf16_t*)C + (long)blockIdx.y * c_batch_stride + (long)row * ldc + n;
+        if (n + 3 < N && (ldc & 3) == 0 && ((((uintptr_t)C) & 7) == 0) && (c_batch_stride & 3) == 0) {
+            const bf16x4_t t = {(bf16_t)(v[0] * alpha), (bf16_t)(v[1] * alpha), (bf16_t)(v[2] * alpha), (bf16_t)(v[3] * alpha)};
+            *(bf16x4_t*)c = t;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) c[r] = (bf16_t)(v[r] * alpha);
+        }
         return;
     }
     float* c = C + (long)blockIdx.y * c_batch_stride + (long)row * ldc + n;

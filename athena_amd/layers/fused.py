@@ -69,8 +69,12 @@ def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=
         kc = ops.roundup(N, 8)    # padding columns of dy and of the shadow are zero
         if lddy < kc:
             raise RuntimeError("lin_bwd_x: dy leading dimension %d < %d" % (lddy, kc))
+        # a plain product with few rows and a long contraction (the vocabulary projection of the
+        # decoder: 1056 x 256 x 4240 is 17 workgroups) is left to split its contraction
+        plain = act == ACT_NONE and aux is None and not accumulate and drop_p == 0.0
         ops.gemm(dy, dense.shadow, out, M, K, kc, trans_b=True, lda=lddy, ldb=dense.shadow.shape[1], ldc=K,
-                 act=act, aux=aux, ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site)
+                 act=act, aux=aux, ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site,
+                 split_k=0 if (plain and kc >= 2048) else 1)
     else:
         ops.gemm(dy, dense.kernel, out, M, K, N, trans_b=True, lda=lddy, ldb=N, ldc=K, act=act, aux=aux,
                  ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site)

@@ -1071,3 +1071,24 @@ def test_copy_many_device_and_pinned(ops):
         assert torch.equal(s.cpu(), d.cpu())
     with pytest.raises(RuntimeError):
         ops.copy_many([(srcs[0], torch.zeros(2, device=dev()))])
+
+
+@pytest.mark.parametrize("M,N,K", [(1056, 256, 4240), (8000, 256, 4240), (330, 72, 2056), (64, 40, 512)])
+def test_gemm_bf16_output_with_split_contraction(ops, M, N, K):
+    """bf16 operands AND a bf16 output with the contraction left to split (split_k = 0): the partial
+    sums go through the fp32 workspace and the second pass rounds once, so the result equals the
+    unsplit product up to the order of the fp32 additions."""
+    g = torch.Generator().manual_seed(31)
+    a = to_cd(torch.randn(M, K, generator=g, dtype=torch.float64), torch.bfloat16)
+    b = to_cd(torch.randn(N, K, generator=g, dtype=torch.float64) * 0.1, torch.bfloat16)
+    ref = a.double().cpu() @ b.double().cpu().t()
+    c0 = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    c1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, b, c0, M, N, K, trans_b=True)
+    ops.gemm(a, b, c1, M, N, K, trans_b=True, split_k=0)
+    torch.cuda.synchronize()
+    assert_close(c1, ref, 6e-3, "bf16 output, split contraction")        # one bf16 rounding of values up to ~ max|ref|
+    assert float((c1.double() - c0.double()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # an epilogue cannot be split
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b, c1, M, N, K, trans_b=True, split_k=0, bias=torch.zeros(N, device=dev()))
