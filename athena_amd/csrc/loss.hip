@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
         }
     }
     if (t >= logit_len[b]) {
+        if (argmax && threadIdx.x == 0) argmax[row] = 0;
         if constexpr (kGrad) {
             TG* gr = grad + (long)row * ldl;
             for (int c = threadIdx.x * 4; c < ldl; c += 1024) ctc_store4<TG>(gr + c, 0.f, 0.f, 0.f, 0.f);

@@ -40,8 +40,8 @@ class _CTCLossFn(torch.autograd.Function):
         logit_len = logit_len.to(torch.int32).contiguous()
         ws = torch.empty(ops.ctc_workspace_bytes(B, T, U), dtype=torch.uint8, device=logits.device)
         per = torch.empty(B, dtype=torch.float32, device=logits.device)
-        # the pass over the rows also leaves the per-frame arg-max (zero beyond logit_length)
-        best = torch.zeros(B * T, dtype=torch.int32, device=logits.device)
+        # the pass over the rows also leaves the per-frame arg-max (zero beyond logit_length, written by the kernel)
+        best = torch.empty(B * T, dtype=torch.int32, device=logits.device)
         ctx.grad = None
         if upstream and ctx.needs_input_grad[0]:
             gdt = torch.bfloat16 if bf16_grad else torch.float32

@@ -951,10 +951,23 @@ def bf16_grad_wanted(logits):
     return _HANDOVER_DEPTH > 0 and bool(getattr(logits, "_athena_accepts_bf16_grad", False))
 
 
+_STANDIN_POOL = {}      # device -> [zeros(64), next index]
+
+
 def bf16_grad_standin(shape, g16):
-    s = torch.zeros(1, dtype=torch.float32, device=g16.device)     # a second consumer of the logits sees zeros, not noise
-    # the entry keeps the stand-in's storage alive, so no other tensor can have its address
-    # while the entry exists
+    # a second consumer of the logits sees zeros, not noise.  The stand-ins are elements of one
+    # zero-filled buffer per device that lives for good (no fill launch per step, and no other tensor
+    # can ever have a stand-in's address); an element is not handed out again while its entry exists
+    pool = _STANDIN_POOL.get(g16.device)
+    if pool is None:
+        pool = _STANDIN_POOL[g16.device] = [torch.zeros(64, dtype=torch.float32, device=g16.device), 0]
+    for _ in range(64):
+        s = pool[0][pool[1]:pool[1] + 1]
+        pool[1] = (pool[1] + 1) % 64
+        if s.data_ptr() not in _BF16_GRADS:
+            break
+    else:
+        s = torch.zeros(1, dtype=torch.float32, device=g16.device)
     _BF16_GRADS[s.data_ptr()] = (s, g16)
     return s.expand(shape)
 

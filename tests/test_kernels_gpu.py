@@ -620,12 +620,12 @@ def test_ctc_loss_and_grad_fp32(ops, B, T, V, U):
     ops.ctc_loss_fwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, per, ws, argmax=best)
     assert_close(per, loss_ref, 1e-5, "ctc loss")
     # the per-frame arg-max that the same pass leaves for the accuracy metric: exact inside
-    # logit_length, untouched beyond
+    # logit_length, zero beyond
     want = lt.argmax(-1)
     got = best.view(B, T).cpu()
     for b in range(B):
         assert got[b, :tlen[b]].tolist() == want[b, :tlen[b]].tolist()
-        assert (got[b, tlen[b]:] == -7).all()
+        assert (got[b, tlen[b]:] == 0).all()
     grad = torch.full((B, T, ldl), float("nan"), dtype=torch.float32, device=dev())
     gs = torch.tensor([0.5], dtype=torch.float32, device=dev())
     ops.ctc_loss_bwd(buf, ldl, lab_d, ll_d, tl_d, B, T, V, Ue, V - 1, gs, 2.0 / B, grad, ws)
