@@ -1,17 +1,21 @@
 // CTC loss (log-softmax + alpha/beta over the blank-augmented lattice + gradient), the
 // label-smoothed cross-entropy, and row argmax.  Bandwidth-bound kernels: each logits row is
-// streamed with 16-byte loads and reduced with wavefront shuffles.
+// streamed with 16-byte loads and reduced inside the wavefront by DPP steps.
 //
-// CTC is three kernels:
-//   ctc_fwd    : the lattice workgroups (one per sample: alpha and beta recursions in two
-//                wavefronts, states in registers, probabilities in double precision) and the row
-//                workgroups (logsumexp of one logits row each) in one launch, so the serial
-//                recursion overlaps the streaming pass
-//   ctc_post   : one wave per logits row: the state posterior alpha*beta, normalised, as a short
-//                list (blank, label 1, label 2, ...); one wave per sample: the loss from the
-//                lattice path sum and the row normalisers
-//   ctc_grad   : one workgroup per row: the posterior list scattered by class into an LDS
-//                accumulator, then grad = scale * (softmax - occupancy) streamed out
+// CTC is three launches (loss alone, or loss and gradient from one pass over the logits):
+//   ctc_row     : one workgroup per logits row, the row in registers: logsumexp, first arg-max, the
+//                 emissions of the row's label states (a table of doubles, relative to blank) and,
+//                 on the one-pass path, scale * softmax written as the dense part of the gradient
+//   ctc_lattice : one workgroup per sample: alpha and beta recursions in two wavefronts (states in
+//                 registers, probabilities in double precision with power-of-two rescaling), two
+//                 more wavefronts copying the state vectors from an LDS ring to memory; a sample
+//                 without a path is redone on logarithms the way TensorFlow's dense branch does it
+//   ctc_post    : one wave per logits row: the state posterior alpha*beta, normalised, as a short
+//                 list (blank, label 1, label 2, ...), the loss of each sample, and on the one-pass
+//                 path the gradient columns that have an occupancy
+//   ctc_grad    : the separate backward pass over the posterior list: one workgroup per row, the
+//                 list scattered by class into an LDS accumulator, grad = scale * (softmax -
+//                 occupancy) streamed out
 #include "common.h"
 
 #include <mutex>

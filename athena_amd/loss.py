@@ -33,6 +33,8 @@ class _CTCLossFn(torch.autograd.Function):
     def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False, upstream=None):
         B, T, V = logits.shape
         ctx.bf16_grad = bf16_grad
+        # no zero tensor for the gradient of the arg-max output (the engine would fill one per step)
+        ctx.set_materialize_grads(False)
         U = labels.shape[1]
         src, ldl = _as_padded_rows(logits)
         labels = labels.to(torch.int32).contiguous()
@@ -61,6 +63,8 @@ class _CTCLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _gbest=None):
+        if gout is None:
+            return None, None, None, None, None, None, None
         src, ldl, labels, label_len, logit_len, ws = ctx.saved
         B, T, V, U, blank = ctx.dims
         gs = gout.to(torch.float32).reshape(1).contiguous()
