@@ -51,6 +51,7 @@ class LayerTailFwd(Structure):
         ("site_res1", c_uint32), ("site_ffn", c_uint32), ("site_res2", c_uint32), ("reserved2", c_uint32),
         ("z1", c_void_p), ("y1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("hpre", c_void_p),
         ("h", c_void_p), ("z2", c_void_p), ("y2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p),
+        ("next_w_t", c_void_p * 3), ("next_b", c_void_p * 3), ("next_out", c_void_p * 3),
     ]
 
 

@@ -319,14 +319,21 @@ struct LtFwd {
     bf16_t* y2;
     float* mean2;
     float* rstd2;
+    // optional (QKV): three more products on the layer's output, y2 Wn + bn for the q / k / v
+    // projections of the NEXT layer's self-attention (tiled copies with rows = outputs), while the rows
+    // are still on the CU
+    const bf16_t* wn[3];
+    const float* bn[3];
+    bf16_t* on[3];
 };
 
-template <bool FFN>
+template <bool FFN, bool QKV = false>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd p) {
+    static_assert(FFN || !QKV, "the extra projections follow the feed-forward block");
     // images: [0] ctx, then hidden slices (even)  [1] hidden slices (odd)  [2] y1
     //         [3], [4] staging: x, pre-activation slices (even / odd), z1, z2, y2
     __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 5 : 4][LT_IMG];
-    __shared__ __attribute__((aligned(16))) float vecs[6][LT_D];         // bo gamma1 beta1 b2 gamma2 beta2
+    __shared__ __attribute__((aligned(16))) float vecs[QKV ? 9 : 6][LT_D];   // bo gamma1 beta1 b2 gamma2 beta2 (bq bk bv)
     __shared__ __attribute__((aligned(16))) float b1s[FFN ? LT_MAX_DFF : 4];
     __shared__ float red[2 * 8 * LT_R];
     bf16_t* const img_a = imgs[0];
@@ -357,6 +364,11 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         const int e = tid + t * LT_THREADS;
         bv[t] = (FFN && e < p.dff) ? p.b1[e] : 0.f;
     }
+    float nb[2] = {0.f, 0.f};
+    if constexpr (QKV) {
+        nb[0] = (hi ? p.bn[1] : p.bn[0])[ve];
+        if (!hi) nb[1] = p.bn[2][ve];
+    }
     // ---- weights: the projection, and slice 0 of the first Dense
     LtUnit ua, ub;
     lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
@@ -370,6 +382,10 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     if (FFN) {
 #pragma unroll
         for (int t = 0; t < LT_MAX_DFF / LT_THREADS; ++t) b1s[tid + t * LT_THREADS] = bv[t];
+    }
+    if constexpr (QKV) {
+        vecs[6 + hi][ve] = nb[0];
+        if (!hi) vecs[8][ve] = nb[1];
     }
     __syncthreads();
     LT_STAMP(1);
@@ -417,7 +433,10 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         bf16_t* himg = (c & 1) ? img_h : img_a;
         bf16_t* pimg = (c & 1) ? st1 : st0;
         lt_zero(acc);
-        lt_mul_unit<MORE>(acc, ub, img_y, lane, lt_unit_ptr(p.w1, LT_D, (c + 1) * LT_D + n0, 0, lane), LT_D);  // y1 W1[slice c]
+        // (the last slice requests the next layer's q and k units in place of a next slice's)
+        lt_mul_unit<MORE || QKV>(acc, ub, img_y, lane,
+                                 MORE ? lt_unit_ptr(p.w1, LT_D, (c + 1) * LT_D + n0, 0, lane)
+                                      : lt_unit_ptr(p.wn[0], LT_D, n0, 0, lane), LT_D);          // y1 W1[slice c]
         LT_STAMP(8 + 5 * c);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -445,7 +464,10 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         lt_img_to_global(pimg, p.hpre, p.dff, c * LT_D, row0, p.rows, tid);
         lt_img_to_global(himg, p.h, p.dff, c * LT_D, row0, p.rows, tid);
         LT_STAMP(11 + 5 * c);
-        lt_mul_unit<MORE>(facc, ua, himg, lane, lt_unit_ptr(p.w2, p.dff, n0, (c + 1) * LT_D, lane), p.dff);  // += h[slice c] W2[slice c, :]
+        lt_mul_unit<MORE || QKV>(facc, ua, himg, lane,
+                                 MORE ? lt_unit_ptr(p.w2, p.dff, n0, (c + 1) * LT_D, lane)
+                                      : lt_unit_ptr(p.wn[1], LT_D, n0, 0, lane),
+                                 MORE ? (long)p.dff : (long)LT_D);                              // += h[slice c] W2[slice c, :]
         LT_STAMP(12 + 5 * c);
     };
     for (int c = 0; c + 1 < nslice; ++c) slice(c, std::true_type{});
@@ -468,6 +490,31 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     lt_img_to_global(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
     lt_img_to_global(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
     LT_STAMP(6);
+    if constexpr (QKV) {
+        // ub holds the q unit, ua the k unit; the v unit takes ub's place as that is multiplied.  The
+        // results go into the three images nobody reads any more (the hidden-layer images of the
+        // other parity and y1's) and leave together behind one barrier.
+        bf16_t* const oimg[3] = {(nslice & 1) ? img_a : img_h, (nslice & 1) ? st0 : st1, img_y};
+        auto project = [&](int m, LtUnit& u, auto roll_tag) {
+            lt_zero(acc);
+            lt_mul_unit<decltype(roll_tag)::value>(acc, u, yimg, lane, lt_unit_ptr(p.wn[2], LT_D, n0, 0, lane), LT_D);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + 16 * j + 4 * fq;
+                    const float4 b4 = *(const float4*)(&vecs[6 + m][n]);
+                    const float o[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+                    lt_store4(oimg[m] + lt_img_off(16 * i + fr, n), o);
+                }
+        };
+        project(0, ub, std::true_type{});
+        project(1, ua, std::false_type{});
+        project(2, ub, std::false_type{});
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 3; ++m) lt_img_to_global(oimg[m], p.on[m], LT_D, 0, row0, p.rows, tid);
+    }
 }
 
 // ------------------------------------------------------------------------------------- backward
@@ -775,7 +822,20 @@ extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena
     p.z1 = (bf16_t*)d->z1; p.y1 = (bf16_t*)d->y1; p.mean1 = d->mean1; p.rstd1 = d->rstd1;
     p.hpre = (bf16_t*)d->hpre; p.h = (bf16_t*)d->h;
     p.z2 = (bf16_t*)d->z2; p.y2 = (bf16_t*)d->y2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
-    if (d->dff > 0)
+    const bool qkv = d->next_w_t[0] != nullptr;
+    for (int m = 0; m < 3; ++m) {
+        ATHENA_REQUIRE(!qkv || (d->dff > 0 && d->next_w_t[m] && d->next_b[m] && d->next_out[m] && lt_al16(d->next_w_t[m]) &&
+                                lt_al16(d->next_out[m])),
+                       ATHENA_E_SHAPE, "athena_layer_tail_fwd: the three extra projections need the feed-forward block, "
+                                       "weights, biases and 16-byte aligned outputs");
+        p.wn[m] = (const bf16_t*)d->next_w_t[m];
+        p.bn[m] = d->next_b[m];
+        p.on[m] = (bf16_t*)d->next_out[m];
+    }
+    if (qkv)
+        hipLaunchKernelGGL((layer_tail_fwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    else if (d->dff > 0)
         hipLaunchKernelGGL(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     else

@@ -41,9 +41,10 @@ class MultiHeadAttention(nn.Module):
         self.store, self.d_model, self.num_heads = store, d_model, num_heads
         self.depth = d_model // num_heads
         init = truncated_normal(0.02)
-        self.wq = Dense(store, name + ".wq", d_model, d_model, init)
-        self.wk = Dense(store, name + ".wk", d_model, d_model, init)
-        self.wv = Dense(store, name + ".wv", d_model, d_model, init)
+        # (tiled copies: the layer in front can run these three projections in its one-launch tail)
+        self.wq = Dense(store, name + ".wq", d_model, d_model, init, tiled=True)
+        self.wk = Dense(store, name + ".wk", d_model, d_model, init, tiled=True)
+        self.wv = Dense(store, name + ".wv", d_model, d_model, init, tiled=True)
         self.dense = Dense(store, name + ".dense", d_model, d_model, init, tiled=True)
         # one fused bf16 copy [d, 3d] of the three projection kernels: the input gradients of the
         # projections that share an input are then a single product

@@ -151,12 +151,15 @@ def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):
 # ----------------------------------------------------------------------------------------------
 # Multi-head attention block (reference athena/layers/attention.py:147-171)
 # ----------------------------------------------------------------------------------------------
-def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True):
-    """q/k/v projections, attention and (``project``) the output projection.  Without it the
-    attention context is returned in place of the block's output."""
+def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True, qkv=None):
+    """q/k/v projections (unless the caller brings them: ``qkv``), attention and (``project``) the
+    output projection.  Without it the attention context is returned in place of the block's output."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
-    q, k, v = lin_fwd_group([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk), (kv_in, B * Tk, attn.wv)])
+    if qkv is not None:
+        q, k, v = qkv
+    else:
+        q, k, v = lin_fwd_group([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk), (kv_in, B * Tk, attn.wv)])
     ctx = torch.empty((B * Tq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, h, Tq), dtype=torch.float32, device=q.device)
     ops.mha_fwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, d, lse)
@@ -280,11 +283,28 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.layer, ctx.key_mask, ctx.p, ctx.shape = layer, key_mask, p, (B, T, d)
         ctx.tail = None
         if ops.layer_tail_ok(x2, d, layer.self_attn.dense, layer.ffn0, layer.ffn1):
-            # everything after the attention kernel in one launch
-            c, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, layer.self_attn.band, project=False)
-            t = ops.layer_tail_fwd(c, x2.contiguous(), layer.self_attn.dense, layer.norm1, layer.ffn0, layer.ffn1,
-                                   layer.norm2, LN_EPS, p, rng, layer.site_res1, layer.site_ffn_h, layer.site_res2)
+            # everything after the attention kernel in one launch -- and, when the encoder stack has
+            # linked the layers, the q / k / v projections of the layer behind this one as well, which
+            # that layer then finds waiting (its backward pass is the same either way: it keeps q, k, v)
+            x2 = x2.contiguous()
+            pre = layer.__dict__.pop("_pre_qkv", None)
+            if pre is not None and (pre[0] != x2.data_ptr() or pre[1] != (M, d)):
+                pre = None
+            c, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, layer.self_attn.band, project=False,
+                                     qkv=pre[2] if pre is not None else None)
+            nxt = layer.__dict__.get("_next_in_stack")
+            nxt = nxt[0] if nxt else None
+            nq = None
+            if nxt is not None and ops.layer_tail_ok(x2, d, nxt.self_attn.dense, nxt.ffn0, nxt.ffn1) and \
+                    all(m.tiled_t is not None for m in (nxt.self_attn.wq, nxt.self_attn.wk, nxt.self_attn.wv)) and \
+                    os.environ.get("ATHENA_TAIL_QKV", "1") != "0":
+                nq = (nxt.self_attn.wq, nxt.self_attn.wk, nxt.self_attn.wv)
+            t = ops.layer_tail_fwd(c, x2, layer.self_attn.dense, layer.norm1, layer.ffn0, layer.ffn1,
+                                   layer.norm2, LN_EPS, p, rng, layer.site_res1, layer.site_ffn_h, layer.site_res2,
+                                   next_qkv=nq)
             y2 = t.pop("y2")
+            if nq is not None:
+                nxt.__dict__["_pre_qkv"] = (y2.data_ptr(), (M, d), (t.pop("q"), t.pop("k"), t.pop("v")))
             ctx.tail = t
             ctx.saved = (x2, s_att)
             return y2.view(B, T, d)

@@ -67,11 +67,18 @@ class TransformerEncoder(nn.Module):
     def __init__(self, encoder_layers):
         super().__init__()
         self.layers = nn.ModuleList(encoder_layers)
+        # a layer's one-launch tail can run the q / k / v projections of the layer behind it (a list
+        # around the reference keeps the layer from being registered as a sub-module twice)
+        for a, b in zip(encoder_layers[:-1], encoder_layers[1:]):
+            if hasattr(a, "self_attn") and hasattr(b, "self_attn"):
+                a.__dict__["_next_in_stack"] = [b]
 
     def forward(self, src, src_mask=None, training=None):
         output = src
         n = len(self.layers)
         store = getattr(self.layers[0], "store", None) if n else None
+        for layer in self.layers:
+            layer.__dict__.pop("_pre_qkv", None)          # nothing left over from a pass that did not finish
         for i, layer in enumerate(self.layers):
             output = layer(output, src_mask=src_mask, training=training)
             # cut points for a pipelined backward pass: after every third of the stack

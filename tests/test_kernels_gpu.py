@@ -1009,6 +1009,82 @@ def test_layer_tail_matches_separate_kernels(ops, monkeypatch, dff, B, T, rate):
         assert rel_l2(g1[name], g0[name]) < 1.5e-2, (name, rel_l2(g1[name], g0[name]))
 
 
+def _encoder_stack_run(monkeypatch, fold, dff, B, T, rate, nlayers=3, seed=9):
+    """Forward + backward pass of a bf16 encoder stack (d_model 256); ``fold``: the tail of a layer
+    runs the q / k / v projections of the layer behind it."""
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerEncoder, TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    monkeypatch.setenv("ATHENA_LAYER_TAIL", "1")
+    monkeypatch.setenv("ATHENA_TAIL_QKV", "1" if fold else "0")
+    store = ParamStore(torch.bfloat16, device=dev())
+    enc = TransformerEncoder([TransformerEncoderLayer(store, "enc.%d" % i, 256, 4, dff, rate) for i in range(nlayers)])
+    store.finalize(seed=seed)
+    bind_all(enc)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p_ in enc.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.3 * torch.randn(p_.shape, generator=g).to(p_.device))
+    store.refresh_shadows(force=True)
+    x = torch.randn(B, T, 256, generator=g).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(B, T, 256, generator=g).to(dev()).to(torch.bfloat16)
+    store.grads.zero_()
+    y = enc(x, None, training=True)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    grads = {n: p_.grad.detach().float().clone() for n, p_ in enc.named_parameters()}
+    return y.detach().float(), x.grad.detach().float(), grads
+
+
+@pytest.mark.parametrize("dff,B,T,rate", [(1024, 4, 64, 0.0), (512, 3, 50, 0.1), (768, 1, 7, 0.1)])
+def test_layer_tail_runs_the_next_layers_projections(ops, monkeypatch, dff, B, T, rate):
+    """A stack whose layer tails also run the q / k / v projections of the layer behind them
+    (MultiHeadAttention.call, reference athena/layers/attention.py:150-153) against the same stack
+    with the projections as a launch of their own: the same products on the same bf16 inputs, summed
+    in another order."""
+    y0, dx0, g0 = _encoder_stack_run(monkeypatch, False, dff, B, T, rate)
+    y1, dx1, g1 = _encoder_stack_run(monkeypatch, True, dff, B, T, rate)
+    assert torch.isfinite(y1).all() and torch.isfinite(dx1).all()
+    assert rel_l2(y1, y0) < 4e-3, ("y", rel_l2(y1, y0))
+    assert rel_l2(dx1, dx0) < 1e-2, ("dx", rel_l2(dx1, dx0))
+    for name in g0:
+        if name.endswith("wk.bias"):
+            continue
+        assert rel_l2(g1[name], g0[name]) < 1e-2, (name, rel_l2(g1[name], g0[name]))
+
+
+def test_layer_tail_projection_values(ops):
+    """The three extra products of ``layer_tail_fwd`` against ``y2 @ W + b`` computed from the y2 the
+    same launch wrote."""
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    from athena_amd.layers.fused import LN_EPS
+    store = ParamStore(torch.bfloat16, device=dev())
+    a = TransformerEncoderLayer(store, "a", 256, 4, 512, 0.0)
+    b = TransformerEncoderLayer(store, "b", 256, 4, 512, 0.0)
+    store.finalize(seed=4)
+    bind_all(a)
+    bind_all(b)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in (b.self_attn.wq, b.self_attn.wk, b.self_attn.wv):
+            m.bias.add_(torch.randn(256, generator=g).to(dev()))
+    store.refresh_shadows(force=True)
+    rows = 75
+    c = torch.randn(rows, 256, generator=g).to(dev()).to(torch.bfloat16)
+    x = torch.randn(rows, 256, generator=g).to(dev()).to(torch.bfloat16)
+    nq = (b.self_attn.wq, b.self_attn.wk, b.self_attn.wv)
+    t = ops.layer_tail_fwd(c, x, a.self_attn.dense, a.norm1, a.ffn0, a.ffn1, a.norm2, LN_EPS, 0.0, store.rng_state,
+                           1, 2, 3, next_qkv=nq)
+    torch.cuda.synchronize()
+    y2 = t["y2"].double()
+    for name, m in zip("qkv", nq):
+        want = y2 @ m.kernel.detach().to(torch.bfloat16).double() + m.bias.detach().double()
+        assert_close(t[name], want.cpu(), 6e-3, "tail projection " + name)
+
+
 def test_refresh_shadows(ops):
     from athena_amd.runtime import ParamStore, glorot_uniform
     st = ParamStore(torch.bfloat16, device=dev())
