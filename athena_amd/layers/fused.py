@@ -386,14 +386,28 @@ class DecoderLayerFn(torch.autograd.Function):
             # two launches besides the attention kernels and their q/k/v projections: self-attention
             # projection + LayerNorm, then cross-attention projection + LayerNorm + FFN + LayerNorm
             t2 = t2.contiguous()
-            c1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True, project=False)
+            # (the self-attention projections may be waiting: the second tail of the layer in front ran them)
+            pre = layer.__dict__.pop("_pre_qkv", None)
+            if pre is not None and (pre[0] != t2.data_ptr() or pre[1] != (M, d)):
+                pre = None
+            c1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True, project=False,
+                                   qkv=pre[2] if pre is not None else None)
             ta = ops.layer_tail_fwd(c1, t2, layer.attn1.dense, layer.norm1, None, None, None, LN_EPS, p, rng,
                                     layer.site_res1, 0, 0)
             y1 = ta["y1"]
             c2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False, project=False)
+            nxt = layer.__dict__.get("_next_in_stack")
+            nxt = nxt[0] if nxt else None
+            nq = None
+            if nxt is not None and ops.layer_tail_ok(t2, d, nxt.attn1.dense) and \
+                    all(m.tiled_t is not None for m in (nxt.attn1.wq, nxt.attn1.wk, nxt.attn1.wv)) and \
+                    os.environ.get("ATHENA_TAIL_QKV", "1") != "0":
+                nq = (nxt.attn1.wq, nxt.attn1.wk, nxt.attn1.wv)
             tb = ops.layer_tail_fwd(c2, y1, layer.attn2.dense, layer.norm2, layer.ffn0, layer.ffn1, layer.norm3,
-                                    LN_EPS, p, rng, layer.site_res2, layer.site_ffn_h, layer.site_res3)
+                                    LN_EPS, p, rng, layer.site_res2, layer.site_ffn_h, layer.site_res3, next_qkv=nq)
             y3 = tb.pop("y2")
+            if nq is not None:
+                nxt.__dict__["_pre_qkv"] = (y3.data_ptr(), (M, d), (tb.pop("q"), tb.pop("k"), tb.pop("v")))
             ctx.tails = (ta, tb)
             ctx.saved = (t2, m2, s1, s2)
             return y3.view(B, L, d)

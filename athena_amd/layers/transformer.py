@@ -93,9 +93,16 @@ class TransformerDecoder(nn.Module):
     def __init__(self, decoder_layers):
         super().__init__()
         self.layers = nn.ModuleList(decoder_layers)
+        # as in the encoder stack: the last tail of a layer can run the self-attention projections of
+        # the layer behind it
+        for a, b in zip(decoder_layers[:-1], decoder_layers[1:]):
+            if hasattr(a, "attn1") and hasattr(b, "attn1"):
+                a.__dict__["_next_in_stack"] = [b]
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, return_attention_weights=False, training=None):
         output = tgt
+        for layer in self.layers:
+            layer.__dict__.pop("_pre_qkv", None)
         for layer in self.layers:
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, training=training)
         if return_attention_weights:
