@@ -509,11 +509,16 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
                 }
         };
         project(0, ub, std::true_type{});
+        LT_STAMP(28);
         project(1, ua, std::false_type{});
+        LT_STAMP(29);
         project(2, ub, std::false_type{});
+        LT_STAMP(30);
         __syncthreads();
+        LT_STAMP(31);
 #pragma unroll
         for (int m = 0; m < 3; ++m) lt_img_to_global(oimg[m], p.on[m], LT_D, 0, row0, p.rows, tid);
+        LT_STAMP(32);
     }
 }
 
