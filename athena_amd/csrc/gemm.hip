@@ -24,7 +24,7 @@ static int big_tiles_mode() {
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
-extern "C" int athena_abi_version(void) { return 8; }
+extern "C" int athena_abi_version(void) { return 9; }
 
 static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     memset(&e, 0, sizeof(e));
