@@ -66,6 +66,7 @@ class LayerTailBwd(Structure):
         ("site_res1", c_uint32), ("site_ffn", c_uint32), ("site_res2", c_uint32), ("reserved3", c_uint32),
         ("df", c_void_p), ("dh", c_void_p), ("da", c_void_p), ("dx", c_void_p), ("dctx", c_void_p),
         ("slab2", c_void_p), ("slab1", c_void_p),
+        ("add_dqkv", c_void_p), ("add_w", c_void_p * 3),
     ]
 
 

@@ -610,10 +610,17 @@ struct LtBwd {
     bf16_t* dctx;            // gradient of the attention context
     float* slab2;            // [workgroups][2][256]
     float* slab1;
+    // optional (ADD): dy is short of the product add[rows, 768] (aw[0] | aw[1] | aw[2])^T -- the part of
+    // the gradient of this layer's output that comes back through the q / k / v projections of the
+    // layer behind it (add = dq | dk | dv side by side; aw: tiled copies with rows = the projections'
+    // 256 inputs) -- and the kernel adds it before anything else
+    const bf16_t* add;
+    const bf16_t* aw[3];
 };
 
-template <bool FFN>
+template <bool FFN, bool ADD = false>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd p) {
+    static_assert(FFN || !ADD, "the extra product needs the images of the feed-forward part");
     // images: [0] df, later da  [1] z1  [2], [3] dh slices (even / odd); before the slices dy and z2,
     //         after them dx and dctx  [4], [5] pre-activation slices (even / odd)
     __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 6 : 4][LT_IMG];
@@ -640,6 +647,11 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
         lt_tile_load(tz2, p.z2, LT_D, 0, row0, p.rows, tid);
         lt_tile_load(thp, p.hpre, p.dff, 0, row0, p.rows, tid);
     }
+    LtTile tadd[3];
+    if constexpr (ADD) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) lt_tile_load(tadd[m], p.add, 3 * LT_D, m * LT_D, row0, p.rows, tid);
+    }
     const bool hi = tid >= LT_D;
     const int ve = tid & (LT_D - 1);
     float gv = 0.f, sv = 0.f;
@@ -653,9 +665,17 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     LtUnit ua, ub;
     if (FFN) lt_load_unit(ua, lt_unit_ptr(p.w2, LT_D, n0, 0, lane), LT_D);       // rows of slice 0 of W2, k over d
     else lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
+    if constexpr (ADD) lt_load_unit(ub, lt_unit_ptr(p.aw[0], LT_D, n0, 0, lane), LT_D);
     __builtin_amdgcn_sched_barrier(0);
     lt_tile_to_img(img_z1, tz1, tid);
     lt_tile_to_img(img_h0, tdy, tid);
+    // dq, dk, dv rows: the two images nothing uses yet and the parking space of dz2 (written only
+    // behind the barrier inside the first LayerNorm')
+    bf16_t* const img_add[3] = {imgs[0], imgs[FFN ? 5 : 0], reinterpret_cast<bf16_t*>(&park[0][0])};
+    if constexpr (ADD) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) lt_tile_to_img(img_add[m], tadd[m], tid);
+    }
     if (FFN) {
         lt_tile_to_img(img_h1, tz2, tid);
         lt_tile_to_img(imgs[4], thp, tid);
@@ -677,6 +697,19 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
             for (int r = 0; r < 4; ++r) g[i][j][r] = (float)t[r];
             if (FFN) zv[i][j] = lt_img_get4(img_h1, 16 * i + fr, n);
         }
+    if constexpr (ADD) {
+        f32x4_t aacc[2][2];
+        lt_zero(aacc);
+        lt_mul_unit<true>(aacc, ub, img_add[0], lane, lt_unit_ptr(p.aw[1], LT_D, n0, 0, lane), LT_D);
+        lt_mul_unit<true>(aacc, ub, img_add[1], lane, lt_unit_ptr(p.aw[2], LT_D, n0, 0, lane), LT_D);
+        lt_mul_unit<false>(aacc, ub, img_add[2], lane, nullptr, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[i][j][r] += aacc[i][j][r];
+    }
     uint64_t key = 0;
     if (FFN) {
         lt_ln_bwd(g, zv, stat[0], stat[1], gam[0], row0, p.rows, wave, lane, red,
@@ -880,7 +913,17 @@ extern "C" int athena_layer_tail_bwd(const athena_layer_tail_bwd_desc* d, athena
     p.site_res1 = d->site_res1; p.site_ffn = d->site_ffn; p.site_res2 = d->site_res2;
     p.df = (bf16_t*)d->df; p.dh = (bf16_t*)d->dh; p.da = (bf16_t*)d->da; p.dx = (bf16_t*)d->dx;
     p.dctx = (bf16_t*)d->dctx; p.slab2 = d->slab2; p.slab1 = d->slab1;
-    if (d->dff > 0)
+    const bool add = d->add_dqkv != nullptr;
+    ATHENA_REQUIRE(!add || (d->dff > 0 && d->add_w[0] && d->add_w[1] && d->add_w[2] && lt_al16(d->add_dqkv) &&
+                            lt_al16(d->add_w[0]) && lt_al16(d->add_w[1]) && lt_al16(d->add_w[2])),
+                   ATHENA_E_SHAPE, "athena_layer_tail_bwd: the extra product needs the feed-forward part, three weight "
+                                   "copies and 16-byte aligned operands");
+    p.add = (const bf16_t*)d->add_dqkv;
+    for (int m = 0; m < 3; ++m) p.aw[m] = (const bf16_t*)d->add_w[m];
+    if (add)
+        hipLaunchKernelGGL((layer_tail_bwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    else if (d->dff > 0)
         hipLaunchKernelGGL(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     else

@@ -170,9 +170,11 @@ def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True, 
 
 
 def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, dq_in, acc_q, dkv_in, acc_kv,
-                  dctx=None):
+                  dctx=None, hand_over=None):
     """Writes parameter grads; adds/stores the input grads into dq_in / dkv_in (may be one tensor).
-    With ``dctx`` (the gradient of the attention context) the output projection is the caller's."""
+    With ``dctx`` (the gradient of the attention context) the output projection is the caller's.
+    ``hand_over``: a callable that takes the self-attention's dq | dk | dv buffer and sees to the
+    product with the fused kernels itself (the input gradient is then short of it on return)."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
     q, k, v, ctx, lse = saved
@@ -208,7 +210,9 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
     lin_bwd_w(q_in, dq, Mq, attn.wq, d, lddq)
     lin_bwd_w(kv_in, dk_, Mk, attn.wk, d, ld)
     lin_bwd_w(kv_in, dv, Mk, attn.wv, d, ld)
-    if fused is not None and same_in:
+    if fused is not None and same_in and hand_over is not None and acc_q:
+        hand_over(dqkv)
+    elif fused is not None and same_in:
         ops.gemm(dqkv, fused, dq_in, Mq, d, 3 * d, trans_b=True, lda=3 * d, ldb=3 * d, ldc=d, accumulate=acc_q)
     elif fused is not None:
         lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
@@ -245,13 +249,29 @@ def _params_of(*mods):
     return ps
 
 
-def _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng):
-    """Backward pass of an encoder layer whose forward pass ran ``ops.layer_tail_fwd``."""
+def _add_pending(pend, dy):
+    """dy += dqkv (wq | wk | wv)^T of the layer behind: the product that layer handed over, as a
+    launch of its own."""
+    dqkv, attn = pend[2], pend[3]
+    M, d = dy.shape
+    ops.gemm(dqkv, attn.qkv_shadow(), dy, M, d, 3 * d, trans_b=True, lda=3 * d, ldb=3 * d, ldc=d, accumulate=True)
+
+
+def _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng, pend=None, hand_over=None):
+    """Backward pass of an encoder layer whose forward pass ran ``ops.layer_tail_fwd``.  ``pend``: what
+    the layer behind handed over (see ``EncoderLayerFn.backward``); ``hand_over``: where this layer's
+    own dq | dk | dv goes instead of into a product here."""
     M, d = dy.shape
     dff = layer.ffn0.out_features
     attn = layer.self_attn
+    add = None
+    if pend is not None:
+        a2 = pend[3]
+        add = (pend[2], (a2.wq, a2.wk, a2.wv))
     r = ops.layer_tail_bwd(dy, t, attn.dense, layer.norm1, layer.ffn0, layer.ffn1, layer.norm2, p, rng,
-                           layer.site_res1, layer.site_ffn_h, layer.site_res2)
+                           layer.site_res1, layer.site_ffn_h, layer.site_res2, add=add)
+    if r is None and pend is not None:
+        _add_pending(pend, dy)
     with weight_grad_group():
         if r is None:
             # no backward pass to fold the LayerNorm sums at the end of: the separate kernels
@@ -266,7 +286,8 @@ def _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng):
         lin_bwd_w(t["h"], df, M, layer.ffn1, dff, d)
         lin_bwd_w(t["y1"], dh, M, layer.ffn0, d, dff)
         lin_bwd_w(s_att[3], da, M, attn.dense, d, d)
-        mha_block_bwd(None, x2, x2, attn, s_att, B, T, T, key_mask, attn.band, dx, True, dx, True, dctx=dctx)
+        mha_block_bwd(None, x2, x2, attn, s_att, B, T, T, key_mask, attn.band, dx, True, dx, True, dctx=dctx,
+                      hand_over=(lambda dqkv: hand_over(dx, dqkv)) if hand_over is not None else None)
     return dx
 
 
@@ -324,11 +345,27 @@ class EncoderLayerFn(torch.autograd.Function):
         M = B * T
         rng = layer.store.rng_state
         dy = dy.contiguous().view(M, d)
+        # The layer behind this one may have handed over the last product of its backward pass,
+        # dq | dk | dv times its fused projection kernels, which is part of THIS layer's output
+        # gradient: the one-launch tail adds it at its start; any other path adds it here and now.
+        pend = layer.__dict__.pop("_pending_dx", None)
+        if pend is not None and (ctx.tail is None or pend[0] != dy.data_ptr() or pend[1] != (M, d)):
+            _add_pending(pend, dy)
+            pend = None
         if ctx.tail is not None:
             t, ctx.tail = ctx.tail, None
             x2, s_att = ctx.saved
             ctx.saved = None
-            dx = _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng)
+            # and this layer hands its own to the layer in front, if that one has a tail to add it in
+            prev = layer.__dict__.get("_prev_in_stack")
+            prev = prev[0] if prev else None
+            hand_over = None
+            if prev is not None and ctx.needs_input_grad[0] and os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and \
+                    ops.layer_tail_ok(x2, d, prev.self_attn.dense, prev.ffn0, prev.ffn1) and \
+                    all(m.tiled is not None for m in (layer.self_attn.wq, layer.self_attn.wk, layer.self_attn.wv)):
+                def hand_over(dx, dqkv, prev=prev, attn=layer.self_attn):
+                    prev.__dict__["_pending_dx"] = (dx.data_ptr(), tuple(dx.shape), dqkv, attn)
+            dx = _encoder_tail_bwd(dy, t, x2, s_att, layer, B, T, key_mask, p, rng, pend, hand_over)
             return (dx.view(B, T, d), None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
         x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2 = ctx.saved
         ctx.saved = None

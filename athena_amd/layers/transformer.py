@@ -72,6 +72,7 @@ class TransformerEncoder(nn.Module):
         for a, b in zip(encoder_layers[:-1], encoder_layers[1:]):
             if hasattr(a, "self_attn") and hasattr(b, "self_attn"):
                 a.__dict__["_next_in_stack"] = [b]
+                b.__dict__["_prev_in_stack"] = [a]     # backward: b hands its last product to a's tail
 
     def forward(self, src, src_mask=None, training=None):
         output = src
@@ -79,6 +80,7 @@ class TransformerEncoder(nn.Module):
         store = getattr(self.layers[0], "store", None) if n else None
         for layer in self.layers:
             layer.__dict__.pop("_pre_qkv", None)          # nothing left over from a pass that did not finish
+            layer.__dict__.pop("_pending_dx", None)
         for i, layer in enumerate(self.layers):
             output = layer(output, src_mask=src_mask, training=training)
             # cut points for a pipelined backward pass: after every third of the stack

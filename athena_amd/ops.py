@@ -384,11 +384,13 @@ def layer_tail_fwd(ctx, x, proj, norm1, ffn0, ffn1, norm2, eps, drop_p, rng_stat
     return out
 
 
-def layer_tail_bwd(dy, saved, proj, norm1, ffn0, ffn1, norm2, drop_p, rng_state, site_res1, site_ffn, site_res2):
+def layer_tail_bwd(dy, saved, proj, norm1, ffn0, ffn1, norm2, drop_p, rng_state, site_res1, site_ffn, site_res2,
+                   add=None):
     """Backward pass of ``layer_tail_fwd`` in one launch (``saved`` is what that returned).  Returns
     (df, dh, da, dx, dctx); df and dh are None without a feed-forward part.  The LayerNorm parameter
     gradients are complete when the enclosing backward pass ends (see ``_LnFolds``); outside one the
-    call is refused (returns None) and the caller runs the separate kernels."""
+    call is refused (returns None) and the caller runs the separate kernels.  ``add`` = (dqkv [rows, 3d],
+    (wq, wk, wv)): ``dy`` is short of dqkv (wq | wk | wv)^T and the launch adds it first."""
     lib = _lib.load()
     rows, d = dy.shape
     dff = ffn0.out_features if ffn0 is not None else 0
@@ -423,6 +425,15 @@ def layer_tail_bwd(dy, saved, proj, norm1, ffn0, ffn1, norm2, drop_p, rng_state,
     dsc.drop_p, dsc.rng_state = drop_p, _ptr(rng_state) if drop_p > 0.0 else None
     dsc.site_res1, dsc.site_ffn, dsc.site_res2 = site_res1, site_ffn, site_res2
     dsc.da, dsc.dx, dsc.dctx, dsc.slab1 = _ptr(da), _ptr(dx), _ptr(dctx), slab1.data_ptr()
+    if add is not None:
+        dqkv, mats = add
+        if not dff or not (dqkv.is_contiguous() and dqkv.dtype == torch.bfloat16 and dqkv.shape == (rows, 3 * d)) or \
+                len(mats) != 3 or any(m.tiled is None or m.in_features != d or m.out_features != d for m in mats):
+            raise RuntimeError("athena_amd.layer_tail_bwd: add needs the feed-forward part, a contiguous bf16 "
+                               "[rows, 3 d] gradient and three tiled d x d Dense layers")
+        dsc.add_dqkv = _ptr(dqkv)
+        for i, m in enumerate(mats):
+            dsc.add_w[i] = _ptr(m.tiled)
     _lib.check(lib.athena_layer_tail_bwd(ctypes.byref(dsc), _stream()), "athena_layer_tail_bwd")
     return df, dh, da, dx, dctx
 
