@@ -468,13 +468,19 @@ class DecoderLayerFn(torch.autograd.Function):
         M = B * L
         rng = layer.store.rng_state
         dy = dy.contiguous().view(M, d)
+        # (as in the encoder: the layer behind may have handed over its self-attention's last product)
+        pend = layer.__dict__.pop("_pending_dx", None)
+        if pend is not None and (ctx.tails is None or pend[0] != dy.data_ptr() or pend[1] != (M, d)):
+            _add_pending(pend, dy)
+            pend = None
         if ctx.tails is not None:
             (ta, tb), ctx.tails = ctx.tails, None
             t2, m2, s1, s2 = ctx.saved
             ctx.saved = None
             dff = layer.ffn0.out_features
+            add = (pend[2], (pend[3].wq, pend[3].wk, pend[3].wv)) if pend is not None else None
             rb = ops.layer_tail_bwd(dy, tb, layer.attn2.dense, layer.norm2, layer.ffn0, layer.ffn1, layer.norm3, p, rng,
-                                    layer.site_res2, layer.site_ffn_h, layer.site_res3)
+                                    layer.site_res2, layer.site_ffn_h, layer.site_res3, add=add)
             if rb is None:
                 raise RuntimeError("decoder layer: the one-launch backward pass needs a running autograd pass")
             df, dh, da2, d_y1, dctx2 = rb
@@ -500,7 +506,17 @@ class DecoderLayerFn(torch.autograd.Function):
                 raise RuntimeError("decoder layer: the one-launch backward pass needs a running autograd pass")
             _, _, da1, dtgt, dctx1 = ra
             lin_bwd_w(s1[3], da1, M, layer.attn1.dense, d, d)
-            mha_block_bwd(None, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True, dctx=dctx1)
+            prev = layer.__dict__.get("_prev_in_stack")
+            prev = prev[0] if prev else None
+            hand_over = None
+            if prev is not None and ctx.needs_input_grad[0] and os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and \
+                    os.environ.get("ATHENA_LAYER_TAIL_DECODER", "1") != "0" and \
+                    ops.layer_tail_ok(t2, d, prev.attn2.dense, prev.ffn0, prev.ffn1) and \
+                    all(m.tiled is not None for m in (layer.attn1.wq, layer.attn1.wk, layer.attn1.wv)):
+                def hand_over(dqkv, prev=prev, attn=layer.attn1, dtgt=dtgt):
+                    prev.__dict__["_pending_dx"] = (dtgt.data_ptr(), tuple(dtgt.shape), dqkv, attn)
+            mha_block_bwd(None, t2, t2, layer.attn1, s1, B, L, L, tgt_key_mask, True, dtgt, True, dtgt, True, dctx=dctx1,
+                          hand_over=hand_over)
             return (dtgt.view(B, L, d), None if dmem is None else dmem.view(B, T, d), None, None, None, None) + \
                 (None,) * (len(ctx.needs_input_grad) - 6)
         t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3 = ctx.saved

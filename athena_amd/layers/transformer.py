@@ -100,11 +100,13 @@ class TransformerDecoder(nn.Module):
         for a, b in zip(decoder_layers[:-1], decoder_layers[1:]):
             if hasattr(a, "attn1") and hasattr(b, "attn1"):
                 a.__dict__["_next_in_stack"] = [b]
+                b.__dict__["_prev_in_stack"] = [a]
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, return_attention_weights=False, training=None):
         output = tgt
         for layer in self.layers:
             layer.__dict__.pop("_pre_qkv", None)
+            layer.__dict__.pop("_pending_dx", None)
         for layer in self.layers:
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, training=training)
         if return_attention_weights:
