@@ -1085,6 +1085,60 @@ def test_layer_tail_projection_values(ops):
         assert_close(t[name], want.cpu(), 6e-3, "tail projection " + name)
 
 
+def _decoder_stack_run(monkeypatch, tails, fold, dff, B, L, T, rate, nlayers=3, seed=11):
+    """Forward + backward pass of a bf16 decoder stack (d_model 256) attending to a memory; ``tails``:
+    the one-launch tails, ``fold``: the projections / the last backward product of a layer's
+    self-attention run by the tails of the layer in front."""
+    from athena_amd.layers.attention import AttnMask
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerDecoder, TransformerDecoderLayer
+    from athena_amd.runtime import ParamStore
+    monkeypatch.setenv("ATHENA_LAYER_TAIL", "1")
+    monkeypatch.setenv("ATHENA_LAYER_TAIL_DECODER", "1" if tails else "0")
+    monkeypatch.setenv("ATHENA_TAIL_QKV", "1" if fold else "0")
+    store = ParamStore(torch.bfloat16, device=dev())
+    dec = TransformerDecoder([TransformerDecoderLayer(store, "dec.%d" % i, 256, 4, dff, rate) for i in range(nlayers)])
+    store.finalize(seed=seed)
+    bind_all(dec)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p_ in dec.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.3 * torch.randn(p_.shape, generator=g).to(p_.device))
+    store.refresh_shadows(force=True)
+    tgt = torch.randn(B, L, 256, generator=g).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    mem = torch.randn(B, T, 256, generator=g).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(B, L, 256, generator=g).to(dev()).to(torch.bfloat16)
+    store.grads.zero_()
+    y = dec(tgt, mem, tgt_mask=AttnMask(None, True), memory_mask=None, training=True)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    grads = {n: p_.grad.detach().float().clone() for n, p_ in dec.named_parameters()}
+    return y.detach().float(), tgt.grad.detach().float(), mem.grad.detach().float(), grads
+
+
+@pytest.mark.parametrize("dff,B,L,T,rate", [(1024, 4, 33, 64, 0.0), (512, 3, 20, 50, 0.1)])
+def test_decoder_tails_and_handed_over_products(ops, monkeypatch, dff, B, L, T, rate):
+    """A decoder stack three ways: separate Dense / LayerNorm launches; one-launch tails; tails that
+    also run the self-attention projections of the layer behind them and, backwards, add the input
+    gradient of those projections (reference athena/layers/transformer.py:374-388).  Same dropout
+    decisions everywhere: the runs differ by bf16 rounding of intermediates."""
+    sep = _decoder_stack_run(monkeypatch, False, False, dff, B, L, T, rate)
+    tails = _decoder_stack_run(monkeypatch, True, False, dff, B, L, T, rate)
+    fold = _decoder_stack_run(monkeypatch, True, True, dff, B, L, T, rate)
+    # (what, candidate, reference, bound on the outputs, bound on the parameter gradients): the tails keep
+    # intermediates in fp32 that the separate launches round to bf16, and three layers of random weights
+    # amplify that; handing products over changes the order of a few fp32 additions only
+    for what, got, ref, tol, tol_g in (("tails", tails, sep, 2e-2, 6e-2), ("fold", fold, tails, 6e-3, 1.2e-2)):
+        for name, a, b in (("y", got[0], ref[0]), ("dtgt", got[1], ref[1]), ("dmem", got[2], ref[2])):
+            assert torch.isfinite(a).all(), name
+            assert rel_l2(a, b) < tol, (what, name, rel_l2(a, b))
+        for name in ref[3]:
+            if name.endswith("wk.bias"):
+                continue
+            assert rel_l2(got[3][name], ref[3][name]) < tol_g, (what, name, rel_l2(got[3][name], ref[3][name]))
+
+
 def test_refresh_shadows(ops):
     from athena_amd.runtime import ParamStore, glorot_uniform
     st = ParamStore(torch.bfloat16, device=dev())
