@@ -174,8 +174,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
                 tmax = fmaxf(tmax, sv);
             }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = rows4_max(tmax);
         const float mn = fmaxf(m, tmax);
         const float alpha = __expf(m - mn);          // first block: exp(-inf) = 0
         m = mn;
@@ -208,8 +207,7 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
         __syncthreads();
     }
     float l = lp;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows4_sum(l);
     if (qi < Tq) {
         const float inv = 1.f / l;
         bf16_t* ob = out + ((long)b * Tq + qi) * ldo + hh * DK + 4 * g;
@@ -258,8 +256,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 8; ++r) del_i += (float)dof[ks][r] * (float)of[r];
     }
-    del_i += __shfl_xor(del_i, 16, 64);
-    del_i += __shfl_xor(del_i, 32, 64);
+    del_i = rows4_sum(del_i);
     const float lse_i = qok ? lse[((long)b * h + hh) * Tq + qi] : INFINITY;
     if (qok && g == 0) delta[((long)b * h + hh) * Tq + qi] = del_i;
     f32x4_t acc[NT];

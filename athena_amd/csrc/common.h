@@ -61,6 +61,22 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// The four lanes l, l ^ 16, l ^ 32, l ^ 48 (one per row of 16 lanes) fold their values: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows (halves) between two registers inside the
+// vector unit, where a shuffle by 16 or 32 lanes is a trip through the LDS crossbar.  With the same
+// value as both operands the two results are, in every lane, the lane's own value and its partner's.
+__device__ __forceinline__ float rows4_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float rows4_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
 // block-wide reductions; ``red`` is LDS scratch of at least 32 floats; all threads get the result
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

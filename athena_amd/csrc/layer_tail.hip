@@ -166,10 +166,8 @@ __device__ __forceinline__ bf16x4_t lt_img_get4(const bf16_t* img, int r, int n)
 __device__ __forceinline__ void lt_row_sums2(float (&a)[2], float (&b)[2], float* red, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        a[i] += __shfl_xor(a[i], 16, 64);
-        b[i] += __shfl_xor(b[i], 16, 64);
-        a[i] += __shfl_xor(a[i], 32, 64);
-        b[i] += __shfl_xor(b[i], 32, 64);
+        a[i] = rows4_sum(a[i]);
+        b[i] = rows4_sum(b[i]);
         if (lane < 16) {
             red[wave * LT_R + 16 * i + lane] = a[i];
             red[8 * LT_R + wave * LT_R + 16 * i + lane] = b[i];
@@ -225,8 +223,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
     float mu[2], q[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        s[i] += __shfl_xor(s[i], 16, 64);
-        s[i] += __shfl_xor(s[i], 32, 64);
+        s[i] = rows4_sum(s[i]);
         const float mw = s[i] * (1.f / 32.f);
         float m2 = 0.f;
 #pragma unroll
@@ -236,8 +233,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
                 const float dv = v[i][j][r] - mw;
                 m2 += dv * dv;
             }
-        m2 += __shfl_xor(m2, 16, 64);
-        m2 += __shfl_xor(m2, 32, 64);
+        m2 = rows4_sum(m2);
         if (lane < 16) {
             red[wave * LT_R + 16 * i + lane] = mw;
             red[8 * LT_R + wave * LT_R + 16 * i + lane] = m2;
