@@ -61,6 +61,18 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// v + (v of the lane a DPP control names): one vector instruction, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_fadd(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over each row of 16 lanes, in every lane of the row (quad swaps, half mirror, mirror)
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_fadd<0xB1>(v);
+    v = dpp_fadd<0x4E>(v);
+    v = dpp_fadd<0x141>(v);
+    return dpp_fadd<0x140>(v);
+}
 // The four lanes l, l ^ 16, l ^ 32, l ^ 48 (one per row of 16 lanes) fold their values: gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange rows (halves) between two registers inside the
 // vector unit, where a shuffle by 16 or 32 lanes is a trip through the LDS crossbar.  With the same

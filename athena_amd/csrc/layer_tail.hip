@@ -561,8 +561,8 @@ __device__ __forceinline__ void lt_ln_bwd(float (&g)[2][2][4], const bf16x4_t (&
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = pg[j][r], b = pb[j][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            a = row16_sum(a);
+            b = row16_sum(b);
             if (fr == 0) {
                 const int n = 32 * wave + 16 * j + 4 * fq + r;
                 slab[n] = a;

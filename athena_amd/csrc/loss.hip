@@ -194,10 +194,6 @@ __device__ __forceinline__ void row_max_sum_arg(const T* __restrict__ row, int V
     m_out = gm;
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_fadd(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
 // sum / maximum over the wave: four DPP steps inside each row of 16 lanes (quad swaps, half mirror,
 // mirror), then the four row results through scalar registers -- no trip through the LDS crossbar
 __device__ __forceinline__ float wave_fsum_dpp(float v) {
