@@ -324,15 +324,13 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
     }
     if (e.colsum && e.atomic != 2) {
         // lanes with equal (lane >> 4) hold the same columns: fold the 16 rows of a lane group by
-        // shuffles, then the two wave rows through LDS; one fp64 atomic per column and statistic
+        // DPP steps, then the two wave rows through LDS; one fp64 atomic per column and statistic
         float* red = (float*)lds;                     // [2 wave rows][256 columns][2]
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = cs[j][r], q = cq[j][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                const float s = row16_sum(cs[j][r]), q = row16_sum(cq[j][r]);
                 if (fr == 0) {
                     const int col = wn * 64 + j * 16 + 4 * fq + r;
                     red[(wm * GB_BN + col) * 2] = s;
