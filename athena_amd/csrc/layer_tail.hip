@@ -616,7 +616,9 @@ struct LtBwd {
 
 template <bool FFN, bool ADD = false>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd p) {
-    static_assert(FFN || !ADD, "the extra product needs the images of the feed-forward part");
+    // products added to dy: dq | dk | dv of a self-attention behind a layer with a feed-forward part,
+    // the dq of the cross-attention behind a decoder's self-attention sub-layer
+    constexpr int NA = FFN ? 3 : 1;
     // images: [0] df, later da  [1] z1  [2], [3] dh slices (even / odd); before the slices dy and z2,
     //         after them dx and dctx  [4], [5] pre-activation slices (even / odd)
     __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 6 : 4][LT_IMG];
@@ -643,10 +645,10 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
         lt_tile_load(tz2, p.z2, LT_D, 0, row0, p.rows, tid);
         lt_tile_load(thp, p.hpre, p.dff, 0, row0, p.rows, tid);
     }
-    LtTile tadd[3];
+    LtTile tadd[NA];
     if constexpr (ADD) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) lt_tile_load(tadd[m], p.add, 3 * LT_D, m * LT_D, row0, p.rows, tid);
+        for (int m = 0; m < NA; ++m) lt_tile_load(tadd[m], p.add, NA * LT_D, m * LT_D, row0, p.rows, tid);
     }
     const bool hi = tid >= LT_D;
     const int ve = tid & (LT_D - 1);
@@ -666,11 +668,12 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     lt_tile_to_img(img_z1, tz1, tid);
     lt_tile_to_img(img_h0, tdy, tid);
     // dq, dk, dv rows: the two images nothing uses yet and the parking space of dz2 (written only
-    // behind the barrier inside the first LayerNorm')
-    bf16_t* const img_add[3] = {imgs[0], imgs[FFN ? 5 : 0], reinterpret_cast<bf16_t*>(&park[0][0])};
+    // behind the barrier inside the first LayerNorm'); without the feed-forward part the one image
+    // that is not used before the end
+    bf16_t* const img_add[3] = {imgs[FFN ? 0 : 3], imgs[FFN ? 5 : 0], reinterpret_cast<bf16_t*>(&park[0][0])};
     if constexpr (ADD) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) lt_tile_to_img(img_add[m], tadd[m], tid);
+        for (int m = 0; m < NA; ++m) lt_tile_to_img(img_add[m], tadd[m], tid);
     }
     if (FFN) {
         lt_tile_to_img(img_h1, tz2, tid);
@@ -696,9 +699,13 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     if constexpr (ADD) {
         f32x4_t aacc[2][2];
         lt_zero(aacc);
-        lt_mul_unit<true>(aacc, ub, img_add[0], lane, lt_unit_ptr(p.aw[1], LT_D, n0, 0, lane), LT_D);
-        lt_mul_unit<true>(aacc, ub, img_add[1], lane, lt_unit_ptr(p.aw[2], LT_D, n0, 0, lane), LT_D);
-        lt_mul_unit<false>(aacc, ub, img_add[2], lane, nullptr, 0);
+        if constexpr (NA == 3) {
+            lt_mul_unit<true>(aacc, ub, img_add[0], lane, lt_unit_ptr(p.aw[1], LT_D, n0, 0, lane), LT_D);
+            lt_mul_unit<true>(aacc, ub, img_add[1], lane, lt_unit_ptr(p.aw[2], LT_D, n0, 0, lane), LT_D);
+            lt_mul_unit<false>(aacc, ub, img_add[2], lane, nullptr, 0);
+        } else {
+            lt_mul_unit<false>(aacc, ub, img_add[0], lane, nullptr, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -910,14 +917,17 @@ extern "C" int athena_layer_tail_bwd(const athena_layer_tail_bwd_desc* d, athena
     p.df = (bf16_t*)d->df; p.dh = (bf16_t*)d->dh; p.da = (bf16_t*)d->da; p.dx = (bf16_t*)d->dx;
     p.dctx = (bf16_t*)d->dctx; p.slab2 = d->slab2; p.slab1 = d->slab1;
     const bool add = d->add_dqkv != nullptr;
-    ATHENA_REQUIRE(!add || (d->dff > 0 && d->add_w[0] && d->add_w[1] && d->add_w[2] && lt_al16(d->add_dqkv) &&
-                            lt_al16(d->add_w[0]) && lt_al16(d->add_w[1]) && lt_al16(d->add_w[2])),
-                   ATHENA_E_SHAPE, "athena_layer_tail_bwd: the extra product needs the feed-forward part, three weight "
-                                   "copies and 16-byte aligned operands");
+    ATHENA_REQUIRE(!add || (d->add_w[0] && lt_al16(d->add_dqkv) && lt_al16(d->add_w[0]) &&
+                            (d->dff == 0 || (d->add_w[1] && d->add_w[2] && lt_al16(d->add_w[1]) && lt_al16(d->add_w[2])))),
+                   ATHENA_E_SHAPE, "athena_layer_tail_bwd: the extra product needs its weight copies (three with a "
+                                   "feed-forward part, one without) and 16-byte aligned operands");
     p.add = (const bf16_t*)d->add_dqkv;
     for (int m = 0; m < 3; ++m) p.aw[m] = (const bf16_t*)d->add_w[m];
-    if (add)
+    if (add && d->dff > 0)
         hipLaunchKernelGGL((layer_tail_bwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    else if (add)
+        hipLaunchKernelGGL((layer_tail_bwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (d->dff > 0)
         hipLaunchKernelGGL(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,

@@ -215,7 +215,10 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
     elif fused is not None and same_in:
         ops.gemm(dqkv, fused, dq_in, Mq, d, 3 * d, trans_b=True, lda=3 * d, ldb=3 * d, ldc=d, accumulate=acc_q)
     elif fused is not None:
-        lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
+        if hand_over is not None and acc_q:
+            hand_over(dq)                       # cross-attention: the query side's product is the caller's
+        else:
+            lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
         ops.gemm(dkv, fused[:, d:], dkv_in, Mk, d, 2 * d, trans_b=True, lda=2 * d, ldb=3 * d, ldc=d,
                  accumulate=acc_kv)
     else:
@@ -496,12 +499,16 @@ class DecoderLayerFn(torch.autograd.Function):
                 if not acc_mem:
                     slot["buf"] = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
                 dmem = slot["buf"]
+            # the cross-attention's dq Wq^T is part of the gradient of y1: the backward tail of the
+            # self-attention sub-layer adds it at its start instead of a launch of its own
+            held = []
+            fold_q = os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and layer.attn2.wq.tiled is not None
             mha_block_bwd(None, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, acc_mem,
-                          dctx=dctx2)
+                          dctx=dctx2, hand_over=held.append if fold_q else None)
             if slot is not None and not _MemoryGrad.leave(slot):
                 dmem = None
             ra = ops.layer_tail_bwd(d_y1, ta, layer.attn1.dense, layer.norm1, None, None, None, p, rng,
-                                    layer.site_res1, 0, 0)
+                                    layer.site_res1, 0, 0, add=(held[0], (layer.attn2.wq,)) if held else None)
             if ra is None:
                 raise RuntimeError("decoder layer: the one-launch backward pass needs a running autograd pass")
             _, _, da1, dtgt, dctx1 = ra

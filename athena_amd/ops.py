@@ -390,7 +390,8 @@ def layer_tail_bwd(dy, saved, proj, norm1, ffn0, ffn1, norm2, drop_p, rng_state,
     (df, dh, da, dx, dctx); df and dh are None without a feed-forward part.  The LayerNorm parameter
     gradients are complete when the enclosing backward pass ends (see ``_LnFolds``); outside one the
     call is refused (returns None) and the caller runs the separate kernels.  ``add`` = (dqkv [rows, 3d],
-    (wq, wk, wv)): ``dy`` is short of dqkv (wq | wk | wv)^T and the launch adds it first."""
+    (wq, wk, wv)) -- without the feed-forward part (dq [rows, d], (wq,)) --: ``dy`` is short of
+    dqkv (wq | wk | wv)^T and the launch adds it first."""
     lib = _lib.load()
     rows, d = dy.shape
     dff = ffn0.out_features if ffn0 is not None else 0
@@ -427,10 +428,11 @@ def layer_tail_bwd(dy, saved, proj, norm1, ffn0, ffn1, norm2, drop_p, rng_state,
     dsc.da, dsc.dx, dsc.dctx, dsc.slab1 = _ptr(da), _ptr(dx), _ptr(dctx), slab1.data_ptr()
     if add is not None:
         dqkv, mats = add
-        if not dff or not (dqkv.is_contiguous() and dqkv.dtype == torch.bfloat16 and dqkv.shape == (rows, 3 * d)) or \
-                len(mats) != 3 or any(m.tiled is None or m.in_features != d or m.out_features != d for m in mats):
-            raise RuntimeError("athena_amd.layer_tail_bwd: add needs the feed-forward part, a contiguous bf16 "
-                               "[rows, 3 d] gradient and three tiled d x d Dense layers")
+        na = 3 if dff else 1
+        if not (dqkv.is_contiguous() and dqkv.dtype == torch.bfloat16 and dqkv.shape == (rows, na * d)) or \
+                len(mats) != na or any(m.tiled is None or m.in_features != d or m.out_features != d for m in mats):
+            raise RuntimeError("athena_amd.layer_tail_bwd: add needs a contiguous bf16 [rows, %d d] gradient and %d "
+                               "tiled d x d Dense layers" % (na, na))
         dsc.add_dqkv = _ptr(dqkv)
         for i, m in enumerate(mats):
             dsc.add_w[i] = _ptr(m.tiled)
