@@ -325,7 +325,9 @@ struct LtFwd {
 
 template <bool FFN, bool QKV = false>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd p) {
-    static_assert(FFN || !QKV, "the extra projections follow the feed-forward block");
+    // extra products on the launch's output: three behind a feed-forward part (q, k, v of the next
+    // layer's self-attention), one without it (the q of the cross-attention that follows a decoder's
+    // self-attention sub-layer)
     // images: [0] ctx, then hidden slices (even)  [1] hidden slices (odd)  [2] y1
     //         [3], [4] staging: x, pre-activation slices (even / odd), z1, z2, y2
     __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 5 : 4][LT_IMG];
@@ -361,9 +363,11 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         bv[t] = (FFN && e < p.dff) ? p.b1[e] : 0.f;
     }
     float nb[2] = {0.f, 0.f};
-    if constexpr (QKV) {
+    if constexpr (QKV && FFN) {
         nb[0] = (hi ? p.bn[1] : p.bn[0])[ve];
         if (!hi) nb[1] = p.bn[2][ve];
+    } else if constexpr (QKV) {
+        if (!hi) nb[0] = p.bn[0][ve];
     }
     // ---- weights: the projection, and slice 0 of the first Dense
     LtUnit ua, ub;
@@ -379,9 +383,11 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
 #pragma unroll
         for (int t = 0; t < LT_MAX_DFF / LT_THREADS; ++t) b1s[tid + t * LT_THREADS] = bv[t];
     }
-    if constexpr (QKV) {
+    if constexpr (QKV && FFN) {
         vecs[6 + hi][ve] = nb[0];
         if (!hi) vecs[8][ve] = nb[1];
+    } else if constexpr (QKV) {
+        if (!hi) vecs[6][ve] = nb[0];
     }
     __syncthreads();
     LT_STAMP(1);
@@ -398,8 +404,11 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     f32x4_t acc[2][2];
     float v[2][2][4];
     lt_zero(acc);
-    // ctx Wo; the projection's registers are refilled with slice 0 of the second Dense
-    lt_mul_unit<FFN>(acc, ua, img_a, lane, lt_unit_ptr(p.w2, p.dff, n0, 0, lane), p.dff);
+    // ctx Wo; the projection's registers are refilled with slice 0 of the second Dense (without a
+    // feed-forward part: with the unit of the one extra product, if there is one)
+    lt_mul_unit<FFN || QKV>(acc, ua, img_a, lane,
+                            FFN ? lt_unit_ptr(p.w2, p.dff, n0, 0, lane) : lt_unit_ptr(p.wn[0], LT_D, n0, 0, lane),
+                            FFN ? (long)p.dff : (long)LT_D);
     LT_STAMP(2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -417,6 +426,23 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     lt_img_to_global(FFN ? st1 : st0, p.z1, LT_D, 0, row0, p.rows, tid);
     lt_img_to_global(img_y, p.y1, LT_D, 0, row0, p.rows, tid);
     LT_STAMP(4);
+    if constexpr (!FFN && QKV) {
+        // y1 Wn + bn into the image the attention context came in (read for the last time before the
+        // barrier above)
+        lt_zero(acc);
+        lt_mul_unit<false>(acc, ua, img_y, lane, nullptr, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + 16 * j + 4 * fq;
+                const float4 b4 = *(const float4*)(&vecs[6][n]);
+                const float o[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+                lt_store4(img_a + lt_img_off(16 * i + fr, n), o);
+            }
+        __syncthreads();
+        lt_img_to_global(img_a, p.on[0], LT_D, 0, row0, p.rows, tid);
+    }
     if (!FFN) return;
 
     // v now holds y1 (the residual of the second half)
@@ -486,7 +512,7 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     lt_img_to_global(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
     lt_img_to_global(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
     LT_STAMP(6);
-    if constexpr (QKV) {
+    if constexpr (QKV && FFN) {
         // ub holds the q unit, ua the k unit; the v unit takes ub's place as that is multiplied.  The
         // results go into the three images nobody reads any more (the hidden-layer images of the
         // other parity and y1's) and leave together behind one barrier.
@@ -865,16 +891,20 @@ extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena
     p.z2 = (bf16_t*)d->z2; p.y2 = (bf16_t*)d->y2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
     const bool qkv = d->next_w_t[0] != nullptr;
     for (int m = 0; m < 3; ++m) {
-        ATHENA_REQUIRE(!qkv || (d->dff > 0 && d->next_w_t[m] && d->next_b[m] && d->next_out[m] && lt_al16(d->next_w_t[m]) &&
-                                lt_al16(d->next_out[m])),
-                       ATHENA_E_SHAPE, "athena_layer_tail_fwd: the three extra projections need the feed-forward block, "
-                                       "weights, biases and 16-byte aligned outputs");
+        ATHENA_REQUIRE(!qkv || (m > 0 && d->dff == 0) ||
+                           (d->next_w_t[m] && d->next_b[m] && d->next_out[m] && lt_al16(d->next_w_t[m]) &&
+                            lt_al16(d->next_out[m])),
+                       ATHENA_E_SHAPE, "athena_layer_tail_fwd: the extra projections (three with a feed-forward part, "
+                                       "one without) need weights, biases and 16-byte aligned outputs");
         p.wn[m] = (const bf16_t*)d->next_w_t[m];
         p.bn[m] = d->next_b[m];
         p.on[m] = (bf16_t*)d->next_out[m];
     }
-    if (qkv)
+    if (qkv && d->dff > 0)
         hipLaunchKernelGGL((layer_tail_fwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    else if (qkv)
+        hipLaunchKernelGGL((layer_tail_fwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (d->dff > 0)
         hipLaunchKernelGGL(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,

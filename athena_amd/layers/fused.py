@@ -152,14 +152,18 @@ def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):
 # Multi-head attention block (reference athena/layers/attention.py:147-171)
 # ----------------------------------------------------------------------------------------------
 def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True, qkv=None):
-    """q/k/v projections (unless the caller brings them: ``qkv``), attention and (``project``) the
-    output projection.  Without it the attention context is returned in place of the block's output."""
+    """q/k/v projections (unless the caller brings them: ``qkv``, a triple whose missing members are
+    None), attention and (``project``) the output projection.  Without it the attention context is
+    returned in place of the block's output."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
-    if qkv is not None:
-        q, k, v = qkv
-    else:
-        q, k, v = lin_fwd_group([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk), (kv_in, B * Tk, attn.wv)])
+    have = list(qkv) if qkv is not None else [None, None, None]
+    todo = [(i, item) for i, item in enumerate([(q_in, B * Tq, attn.wq), (kv_in, B * Tk, attn.wk),
+                                                (kv_in, B * Tk, attn.wv)]) if have[i] is None]
+    if todo:
+        for (i, _), out in zip(todo, lin_fwd_group([item for _, item in todo])):
+            have[i] = out
+    q, k, v = have
     ctx = torch.empty((B * Tq, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, h, Tq), dtype=torch.float32, device=q.device)
     ops.mha_fwd(q, k, v, d, d, d, key_mask, causal, B, h, Tq, Tk, dk, 1.0 / math.sqrt(dk), ctx, d, lse)
@@ -432,10 +436,18 @@ class DecoderLayerFn(torch.autograd.Function):
                 pre = None
             c1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True, project=False,
                                    qkv=pre[2] if pre is not None else None)
+            # the first tail also projects its output for the cross-attention's queries; the keys and
+            # values of the memory may be waiting (the decoder stack projects them for all layers at once)
+            fold = os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and layer.attn2.wq.tiled_t is not None
             ta = ops.layer_tail_fwd(c1, t2, layer.attn1.dense, layer.norm1, None, None, None, LN_EPS, p, rng,
-                                    layer.site_res1, 0, 0)
+                                    layer.site_res1, 0, 0, next_qkv=(layer.attn2.wq,) if fold else None)
             y1 = ta["y1"]
-            c2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False, project=False)
+            q2 = ta.pop("q", None)
+            kv = layer.__dict__.pop("_pre_kv", None)
+            if kv is not None and (kv[0] != m2.data_ptr() or kv[1] != (B * T, d)):
+                kv = None
+            c2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False, project=False,
+                                   qkv=(q2, kv[2][0] if kv else None, kv[2][1] if kv else None))
             nxt = layer.__dict__.get("_next_in_stack")
             nxt = nxt[0] if nxt else None
             nq = None

@@ -1,4 +1,5 @@
 """Post-LN Transformer encoder/decoder (mirror of the reference's athena/layers/transformer.py:27-388)."""
+import torch
 from torch import nn
 
 from ..runtime import truncated_normal
@@ -102,11 +103,34 @@ class TransformerDecoder(nn.Module):
                 a.__dict__["_next_in_stack"] = [b]
                 b.__dict__["_prev_in_stack"] = [a]
 
+    def _project_memory(self, memory):
+        """The key / value projections of the memory for ALL layers' cross-attention as one grouped
+        launch (they depend on nothing a layer computes); each layer finds its pair waiting."""
+        import os
+        from . import fused
+        from .. import ops
+        layers = [l for l in self.layers if hasattr(l, "attn2")]
+        if not layers or memory.dtype != torch.bfloat16 or 2 * len(layers) > 12 or \
+                os.environ.get("ATHENA_TAIL_QKV", "1") == "0" or \
+                os.environ.get("ATHENA_LAYER_TAIL_DECODER", "1") == "0":
+            return
+        B, T, d = memory.shape
+        m2 = memory.reshape(B * T, d)
+        if not all(ops.layer_tail_ok(m2, d, l.attn1.dense) and ops.layer_tail_ok(m2, d, l.attn2.dense, l.ffn0, l.ffn1)
+                   for l in layers):
+            return
+        layers[0].store.refresh_shadows()
+        outs = fused.lin_fwd_group([(m2, B * T, w) for l in layers for w in (l.attn2.wk, l.attn2.wv)])
+        for i, l in enumerate(layers):
+            l.__dict__["_pre_kv"] = (m2.data_ptr(), (B * T, d), (outs[2 * i], outs[2 * i + 1]))
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, return_attention_weights=False, training=None):
         output = tgt
         for layer in self.layers:
             layer.__dict__.pop("_pre_qkv", None)
             layer.__dict__.pop("_pending_dx", None)
+            layer.__dict__.pop("_pre_kv", None)
+        self._project_memory(memory)
         for layer in self.layers:
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, training=training)
         if return_attention_weights:
