@@ -85,6 +85,10 @@ _S = c_void_p   # stream
 _SIGNATURES = {
     "athena_last_error": (c_char_p, []),
     "athena_abi_version": (c_int, []),
+    "athena_timing_begin": (c_int, []),
+    "athena_timing_count": (c_int, []),
+    "athena_timing_end": (c_int, []),
+    "athena_timing_read": (c_int, [c_int, c_int, POINTER(c_float)]),
     "athena_gemm": (c_int, [POINTER(GemmDesc), _S]),
     "athena_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _S]),
     "athena_gemm_wgrad_plan": (c_int, [POINTER(WgradItem), c_int, POINTER(c_int)]),
@@ -157,6 +161,7 @@ _SIGNATURES = {
     "athena_ce_loss_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, c_float, _P, c_int, _S]),
     "athena_group_sum": (c_int, [_P, c_int, c_int, c_float, _P, _S]),
     "athena_argmax_rows": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
+    "athena_seq_errors": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_clip_adam_step": (c_int, [_P, _P, _P, _P, c_long, _P, c_int, _P, _P, POINTER(AdamCfg), _P, _S]),
     "athena_refresh_shadows": (c_int, [_P, _P, _P, c_int, _P, c_long, _S]),
     "athena_advance_rng": (c_int, [_P, _S]),

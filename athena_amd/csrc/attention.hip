@@ -283,13 +283,13 @@ static bool mha_mfma_ok(int dtype, int dk, std::initializer_list<int> lds, std::
 #define MHA_MFMA_DISPATCH(KERNEL, GRID, ...)                                                              \
     do {                                                                                                  \
         if (causal) {                                                                                     \
-            if (dk == 32) hipLaunchKernelGGL((KERNEL<32, true>), GRID, dim3(256), 0, s, __VA_ARGS__);      \
-            else if (dk == 64) hipLaunchKernelGGL((KERNEL<64, true>), GRID, dim3(256), 0, s, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<128, true>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+            if (dk == 32) ATHENA_LAUNCH((KERNEL<32, true>), GRID, dim3(256), 0, s, __VA_ARGS__);      \
+            else if (dk == 64) ATHENA_LAUNCH((KERNEL<64, true>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else ATHENA_LAUNCH((KERNEL<128, true>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
         } else {                                                                                          \
-            if (dk == 32) hipLaunchKernelGGL((KERNEL<32, false>), GRID, dim3(256), 0, s, __VA_ARGS__);     \
-            else if (dk == 64) hipLaunchKernelGGL((KERNEL<64, false>), GRID, dim3(256), 0, s, __VA_ARGS__); \
-            else hipLaunchKernelGGL((KERNEL<128, false>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
+            if (dk == 32) ATHENA_LAUNCH((KERNEL<32, false>), GRID, dim3(256), 0, s, __VA_ARGS__);     \
+            else if (dk == 64) ATHENA_LAUNCH((KERNEL<64, false>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else ATHENA_LAUNCH((KERNEL<128, false>), GRID, dim3(256), 0, s, __VA_ARGS__);             \
         }                                                                                                 \
     } while (0)
 
@@ -297,15 +297,15 @@ static bool mha_mfma_ok(int dtype, int dk, std::initializer_list<int> lds, std::
     do {                                                                                                      \
         switch (dk) {                                                                                         \
             case 8: { constexpr int P = 1; dim3 g((rows + ATT_BLOCK / P - 1) / (ATT_BLOCK / P), h, B);        \
-                hipLaunchKernelGGL((KERNEL<T, 8, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;        \
+                ATHENA_LAUNCH((KERNEL<T, 8, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;        \
             case 16: { constexpr int P = 1; dim3 g((rows + ATT_BLOCK / P - 1) / (ATT_BLOCK / P), h, B);       \
-                hipLaunchKernelGGL((KERNEL<T, 16, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
+                ATHENA_LAUNCH((KERNEL<T, 16, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
             case 32: { constexpr int P = 1; dim3 g((rows + ATT_BLOCK / P - 1) / (ATT_BLOCK / P), h, B);       \
-                hipLaunchKernelGGL((KERNEL<T, 32, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
+                ATHENA_LAUNCH((KERNEL<T, 32, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
             case 64: { constexpr int P = 2; dim3 g((rows + ATT_BLOCK / P - 1) / (ATT_BLOCK / P), h, B);       \
-                hipLaunchKernelGGL((KERNEL<T, 64, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
+                ATHENA_LAUNCH((KERNEL<T, 64, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;       \
             default: { constexpr int P = 4; dim3 g((rows + ATT_BLOCK / P - 1) / (ATT_BLOCK / P), h, B);       \
-                hipLaunchKernelGGL((KERNEL<T, 128, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;      \
+                ATHENA_LAUNCH((KERNEL<T, 128, P>), g, dim3(ATT_BLOCK), 0, s, __VA_ARGS__); } break;      \
         }                                                                                                     \
     } while (0)
 
@@ -358,9 +358,9 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
         return ATHENA_OK;
     }
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(mha_delta_kernel<bf16_t>, gd, dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, ldo, h, Tq, dk, total, delta);
+        ATHENA_LAUNCH(mha_delta_kernel<bf16_t>, gd, dim3(256), 0, s, (const bf16_t*)out, (const bf16_t*)dout, ldo, h, Tq, dk, total, delta);
     else
-        hipLaunchKernelGGL(mha_delta_kernel<float>, gd, dim3(256), 0, s, (const float*)out, (const float*)dout, ldo, h, Tq, dk, total, delta);
+        ATHENA_LAUNCH(mha_delta_kernel<float>, gd, dim3(256), 0, s, (const float*)out, (const float*)dout, ldo, h, Tq, dk, total, delta);
     {
         const int rows = Tq;
         if (dtype == ATHENA_BF16)

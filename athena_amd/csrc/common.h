@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of libathena_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -30,6 +31,23 @@ void athena_set_error(const char* fmt, ...);
             athena_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
             return ATHENA_E_LAUNCH;                                               \
         }                                                                         \
+    } while (0)
+
+// ---------------------------------------------------------------- launches
+// Every kernel of the library is launched through ATHENA_LAUNCH.  While a timing session is open
+// (athena_timing_begin) a launch carries a pair of events that the runtime fills with the kernel's
+// own begin and end timestamps, the figures a profiler reports; otherwise it is a plain launch.
+extern int g_athena_timing_on;
+void athena_timing_next(hipEvent_t* start, hipEvent_t* stop);
+#define ATHENA_LAUNCH(kernel, grid, block, lds, stream, ...)                                              \
+    do {                                                                                                  \
+        if (__builtin_expect(g_athena_timing_on, 0)) {                                                    \
+            hipEvent_t ev_a__, ev_b__;                                                                    \
+            athena_timing_next(&ev_a__, &ev_b__);                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev_a__, ev_b__, 0, __VA_ARGS__);      \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                            \
+        }                                                                                                 \
     } while (0)
 
 static inline bool athena_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -172,9 +172,9 @@ extern "C" int athena_conv2d_wgrad(const void* in, const void* dout, float* dw_h
     if (rc) return rc;
     if (partial) {
         const long work = (long)(Cin + 1) * (p.epi.ldp / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), taps), dim3(256), 0,
+        ATHENA_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), taps), dim3(256), 0,
                            (hipStream_t)stream, (const float*)p.epi.partial, plan.split, Cin, Cout, p.epi.ldp, dw_hwio,
-                           Cout, (long)Cin * Cout, 1.f, (float*)nullptr);
+                           Cout, (long)Cin * Cout, 1.f, (float*)nullptr, 0);
         ATHENA_CHECK_LAUNCH("athena_conv2d_wgrad(split-k reduce)");
     }
     return ATHENA_OK;
@@ -220,7 +220,7 @@ extern "C" int athena_im2col(const void* in, int in_dtype, void* col, int col_dt
     if (blocks > 65536) blocks = 65536;
     hipStream_t s = (hipStream_t)stream;
 #define IM2COL(TI, TO)                                                                                              \
-    hipLaunchKernelGGL((im2col_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, s, (const TI*)in, (TO*)col, rows, \
+    ATHENA_LAUNCH((im2col_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, s, (const TI*)in, (TO*)col, rows, \
                        H, W, Cin, Ho, Wo, KW, K, ldcol, ph, pw, sh, sw)
     if (in_dtype == ATHENA_F32 && col_dtype == ATHENA_F32) IM2COL(float, float);
     else if (in_dtype == ATHENA_F32 && col_dtype == ATHENA_BF16) IM2COL(float, bf16_t);

@@ -163,9 +163,9 @@ extern "C" int athena_conv1_bn_stats(const float* in, const float* w_hwio, int B
     const long npix = (long)B * Ho * Wo;
     long blocks = (npix + 255) / 256;
     if (blocks > FC_MOM_BLOCKS) blocks = FC_MOM_BLOCKS;
-    hipLaunchKernelGGL(fc_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, Ho, Wo, ph, pw, slabs);
-    hipLaunchKernelGGL(fc_moments_fold_kernel, dim3(1), dim3(1024), 0, s, (const double*)slabs, (int)blocks, moments);
-    hipLaunchKernelGGL(fc_colstats_kernel, dim3((Cout + 127) / 128), dim3(128), 0, s, (const double*)moments, w_hwio,
+    ATHENA_LAUNCH(fc_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, B, H, W, Ho, Wo, ph, pw, slabs);
+    ATHENA_LAUNCH(fc_moments_fold_kernel, dim3(1), dim3(1024), 0, s, (const double*)slabs, (int)blocks, moments);
+    ATHENA_LAUNCH(fc_colstats_kernel, dim3((Cout + 127) / 128), dim3(128), 0, s, (const double*)moments, w_hwio,
                        Cout, colstats);
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_stats");
     return ATHENA_OK;
@@ -440,7 +440,7 @@ extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, c
         if (nb > 1024) nb = 1024;
         const dim3 grid((unsigned)nb, (unsigned)(Cout / cbw));
 #define FC_MFMA(NP)                                                                                              \
-    hipLaunchKernelGGL(fc_fwd_mfma_kernel<NP>, grid, dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta, eps, infer, B, \
+    ATHENA_LAUNCH(fc_fwd_mfma_kernel<NP>, grid, dim3(256), 0, s, in, w_hwio, s0, s1, gamma, beta, eps, infer, B, \
                        H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out)
         switch (cbw / 32) {
             case 1: FC_MFMA(1); break;
@@ -455,10 +455,10 @@ extern "C" int athena_conv1_bn_relu6_fwd(const float* in, const float* w_hwio, c
         blocks = (npix - pix_begin + slots - 1) / slots;
         if (blocks > 2048) blocks = 2048;
         if (dtype == ATHENA_BF16)
-            hipLaunchKernelGGL(fc_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
+            ATHENA_LAUNCH(fc_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
                                beta, eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (bf16_t*)out, pix_begin);
         else
-            hipLaunchKernelGGL(fc_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
+            ATHENA_LAUNCH(fc_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, in, w_hwio, s0, s1, gamma,
                                beta, eps, infer, B, H, W, Cout, Ho, Wo, ph, pw, (float*)out, pix_begin);
     }
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_relu6_fwd");
@@ -668,7 +668,7 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* r
     const size_t shm = sizeof(float) * (FC_K + 1) * Cout * (Cout / cpt <= 64 ? 4 : 1);
     ATHENA_REQUIRE(!relu6_out || athena_aligned16(relu6_out), ATHENA_E_ALIGN, "athena_conv1_bn_bwd: relu6_out alignment");
 #define FC_BWD(TT, CC)                                                                                          \
-    hipLaunchKernelGGL((fc_bwd_reduce_kernel<TT, CC>), dim3((unsigned)blocks), dim3(256), shm, s, in, (const TT*)g, \
+    ATHENA_LAUNCH((fc_bwd_reduce_kernel<TT, CC>), dim3((unsigned)blocks), dim3(256), shm, s, in, (const TT*)g, \
                        (const TT*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace)
     if (dtype == ATHENA_BF16) {
         if (cpt == 16) FC_BWD(bf16_t, 16);
@@ -680,9 +680,9 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* r
 #undef FC_BWD
     const int nent = (FC_K + 1) * Cout;
     double* tot = (double*)((char*)workspace + sizeof(float) * (size_t)FC_BWD_BLOCKS * nent);   // 8-byte aligned
-    hipLaunchKernelGGL(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,
+    ATHENA_LAUNCH(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,
                        nent, tot);
-    hipLaunchKernelGGL(fc_bwd_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, (const double*)tot, moments, w_hwio,
+    ATHENA_LAUNCH(fc_bwd_final_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, (const double*)tot, moments, w_hwio,
                        mean_rstd, gamma, npix, Cout, dw_hwio, dgamma, dbeta);
     ATHENA_CHECK_LAUNCH("athena_conv1_bn_bwd");
     return ATHENA_OK;

@@ -2,6 +2,8 @@
 #include "gemm_big.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -24,7 +26,62 @@ static int big_tiles_mode() {
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
-extern "C" int athena_abi_version(void) { return 9; }
+extern "C" int athena_abi_version(void) { return 10; }
+
+// ---------------------------------------------------------------- per-kernel timing sessions
+// Between athena_timing_begin and athena_timing_end every launch of the library carries two events
+// (common.h, ATHENA_LAUNCH); athena_timing_read returns the kernels' own durations in launch order.
+int g_athena_timing_on = 0;
+namespace {
+std::mutex g_timing_mu;
+std::vector<hipEvent_t> g_timing_events;      // start, stop, start, stop, ...
+size_t g_timing_used = 0;
+}  // namespace
+
+void athena_timing_next(hipEvent_t* start, hipEvent_t* stop) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    if (g_timing_used + 2 > g_timing_events.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            g_timing_events.push_back(e);
+        }
+    }
+    *start = g_timing_events[g_timing_used];
+    *stop = g_timing_events[g_timing_used + 1];
+    g_timing_used += 2;
+}
+
+extern "C" int athena_timing_begin(void) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_timing_used = 0;
+    g_athena_timing_on = 1;
+    return ATHENA_OK;
+}
+
+extern "C" int athena_timing_count(void) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    return (int)(g_timing_used / 2);
+}
+
+extern "C" int athena_timing_end(void) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    g_athena_timing_on = 0;
+    return (int)(g_timing_used / 2);
+}
+
+extern "C" int athena_timing_read(int first, int count, float* ms) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    ATHENA_REQUIRE(ms && first >= 0 && count >= 0 && (size_t)(first + count) * 2 <= g_timing_used, ATHENA_E_SHAPE,
+                   "athena_timing_read: launches %d..%d of %zu", first, first + count, g_timing_used / 2);
+    for (int i = 0; i < count; ++i) {
+        hipEvent_t a = g_timing_events[2 * (size_t)(first + i)], b = g_timing_events[2 * (size_t)(first + i) + 1];
+        hipError_t e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[i], a, b);
+        ATHENA_REQUIRE(e == hipSuccess, ATHENA_E_LAUNCH, "athena_timing_read: launch %d: %s", first + i, hipGetErrorString(e));
+    }
+    return ATHENA_OK;
+}
 
 static void fill_epilogue(Epilogue& e, const athena_gemm_desc* d) {
     memset(&e, 0, sizeof(e));
@@ -147,7 +204,7 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     if (use_ws) {
         // the partial sums are added up by a second kernel in a fixed order
         const long work = (long)(d->M + 1) * (p.epi.ldp / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream,
+        ATHENA_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 1), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, d->M, d->N, p.epi.ldp, (float*)d->C, d->ldc, 0L, d->alpha,
                            p.epi.bsum, d->out_dtype == ATHENA_BF16 ? 1 : 0);
         ATHENA_CHECK_LAUNCH("athena_gemm(split-k reduce)");
@@ -158,10 +215,10 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
 template <int WT>
 static void launch_grouped(const GemmGroup& g, bool ta, bool tb, int blocks, hipStream_t stream) {
     const dim3 grid((unsigned)blocks);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, true, WT>), grid, dim3(256), 0, stream, g);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<false, false, WT>), grid, dim3(256), 0, stream, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_grouped_kernel<true, false, WT>), grid, dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_mfma_grouped_kernel<true, true, WT>), grid, dim3(256), 0, stream, g);
+    if (!ta && tb) ATHENA_LAUNCH((gemm_mfma_grouped_kernel<false, true, WT>), grid, dim3(256), 0, stream, g);
+    else if (!ta && !tb) ATHENA_LAUNCH((gemm_mfma_grouped_kernel<false, false, WT>), grid, dim3(256), 0, stream, g);
+    else if (ta && !tb) ATHENA_LAUNCH((gemm_mfma_grouped_kernel<true, false, WT>), grid, dim3(256), 0, stream, g);
+    else ATHENA_LAUNCH((gemm_mfma_grouped_kernel<true, true, WT>), grid, dim3(256), 0, stream, g);
 }
 
 extern "C" int athena_gemm_grouped(const athena_gemm_desc* descs, int count, athena_stream_t stream) {
@@ -266,7 +323,7 @@ extern "C" int athena_gemm_grouped(const athena_gemm_desc* descs, int count, ath
         else launch_grouped<2>(grp, d[0].trans_a != 0, d[0].trans_b != 0, blocks, s);
         ATHENA_CHECK_LAUNCH("athena_gemm_grouped");
         if (red.count > 0) {
-            hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, red);
+            ATHENA_LAUNCH(splitk_reduce_grouped_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, red);
             ATHENA_CHECK_LAUNCH("athena_gemm_grouped(split-k reduce)");
         }
     }
@@ -489,9 +546,9 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
     if (rc) return rc;
     if (partial) {
         const long work = (long)(Cin + 1) * (p.epi.ldp / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 9), dim3(256), 0, (hipStream_t)stream,
+        ATHENA_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((work + 63) / 64), 9), dim3(256), 0, (hipStream_t)stream,
                            (const float*)p.epi.partial, split, Cin, Cout, p.epi.ldp, dw_hwio, Cout, (long)Cin * Cout, 1.f,
-                           (float*)nullptr);
+                           (float*)nullptr, 0);
         ATHENA_CHECK_LAUNCH("athena_conv3x3s2_wgrad(split-k reduce)");
     }
     return ATHENA_OK;
@@ -523,7 +580,7 @@ extern "C" int athena_gemm_wgrad_plan(athena_wgrad_item* items, int count, int* 
 extern "C" int athena_gemm_wgrad_table(const athena_wgrad_item* table_dev, int count, int total_tiles,
                                        athena_stream_t stream) {
     ATHENA_REQUIRE(table_dev && count > 0 && total_tiles > 0, ATHENA_E_SHAPE, "athena_gemm_wgrad_table: empty table");
-    hipLaunchKernelGGL(gemm_big_table_kernel, dim3((unsigned)total_tiles), dim3(GB_THREADS), 0, (hipStream_t)stream,
+    ATHENA_LAUNCH(gemm_big_table_kernel, dim3((unsigned)total_tiles), dim3(GB_THREADS), 0, (hipStream_t)stream,
                        (const GbItem*)table_dev, count);
     ATHENA_CHECK_LAUNCH("athena_gemm_wgrad_table");
     return ATHENA_OK;

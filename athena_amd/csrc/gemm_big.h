@@ -468,7 +468,7 @@ static int launch_gemm_big_multi(const GemmProblem<AMap>* probs, int count, hipS
         tiles += ((m.p[i].M + GB_BM - 1) / GB_BM) * ((m.p[i].N + GB_BN - 1) / GB_BN);
     }
     for (int i = count; i <= GB_MULTI_MAX; ++i) m.first_tile[i] = tiles;
-    hipLaunchKernelGGL((gemm_big_multi_kernel<AMap, false, true>), dim3(tiles), dim3(GB_THREADS), 0, stream, m);
+    ATHENA_LAUNCH((gemm_big_multi_kernel<AMap, false, true>), dim3(tiles), dim3(GB_THREADS), 0, stream, m);
     ATHENA_CHECK_LAUNCH("gemm(large tile, several problems)");
     return ATHENA_OK;
 }
@@ -478,8 +478,8 @@ static int launch_gemm_big(const GemmProblem<AMap>& p, bool ta, bool tb, hipStre
     const int tm = (p.M + GB_BM - 1) / GB_BM, tn = (p.N + GB_BN - 1) / GB_BN;
     const int gz = p.split_k * (p.zbatch > 1 ? p.zbatch : 1);
     const dim3 grid(tm, tn, gz);
-    if (!ta && tb) hipLaunchKernelGGL((gemm_big_kernel<AMap, false, true>), grid, dim3(GB_THREADS), 0, stream, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_big_kernel<AMap, true, false>), grid, dim3(GB_THREADS), 0, stream, p);
+    if (!ta && tb) ATHENA_LAUNCH((gemm_big_kernel<AMap, false, true>), grid, dim3(GB_THREADS), 0, stream, p);
+    else if (ta && !tb) ATHENA_LAUNCH((gemm_big_kernel<AMap, true, false>), grid, dim3(GB_THREADS), 0, stream, p);
     else return ATHENA_E_UNSUPPORTED;
     ATHENA_CHECK_LAUNCH("gemm(large tile)");
     return ATHENA_OK;

@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmProblem<AMap> p) {
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split, int M, int N,
                                                             int ldp, float* __restrict__ C, int ldc,
                                                             long c_batch_stride, float alpha,
-                                                            float* __restrict__ bsum, int c_bf16 = 0) {
+                                                            float* __restrict__ bsum, int c_bf16) {
     // workgroup = 64 column quads x 4 waves; wave w adds slabs w, w + 4, ... and the four partial
     // sums meet in LDS (fixed order: the result does not depend on scheduling)
     __shared__ float4 red[4][64];
@@ -1094,10 +1094,10 @@ static void launch_mfma(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_
         q.xcd_tn = tn;
         grid = dim3((unsigned)((tm + 7) / 8 * 8 * tn), 1, 1);
     }
-    if (!ta && tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, true, WT>), grid, dim3(256), 0, stream, q);
-    else if (!ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, false, false, WT>), grid, dim3(256), 0, stream, q);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, false, WT>), grid, dim3(256), 0, stream, q);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<AMap, true, true, WT>), grid, dim3(256), 0, stream, q);
+    if (!ta && tb) ATHENA_LAUNCH((gemm_mfma_kernel<AMap, false, true, WT>), grid, dim3(256), 0, stream, q);
+    else if (!ta && !tb) ATHENA_LAUNCH((gemm_mfma_kernel<AMap, false, false, WT>), grid, dim3(256), 0, stream, q);
+    else if (ta && !tb) ATHENA_LAUNCH((gemm_mfma_kernel<AMap, true, false, WT>), grid, dim3(256), 0, stream, q);
+    else ATHENA_LAUNCH((gemm_mfma_kernel<AMap, true, true, WT>), grid, dim3(256), 0, stream, q);
 }
 
 // Tile edge and split-K factor for an M x N output with ``k_elems`` contraction elements and
@@ -1152,10 +1152,10 @@ static int launch_gemm(const GemmProblem<AMap>& p, int in_dtype, bool ta, bool t
         else launch_mfma<AMap, 2>(p, ta, tb, stream);
     } else {
         dim3 grid((p.M + GV_BM - 1) / GV_BM, (p.N + GV_BN - 1) / GV_BN, p.split_k * (p.zbatch > 1 ? p.zbatch : 1));
-        if (!ta && tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, false, true>), grid, dim3(256), 0, stream, p);
-        else if (!ta && !tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, false, false>), grid, dim3(256), 0, stream, p);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm_valu_kernel<AMap, true, false>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_valu_kernel<AMap, true, true>), grid, dim3(256), 0, stream, p);
+        if (!ta && tb) ATHENA_LAUNCH((gemm_valu_kernel<AMap, false, true>), grid, dim3(256), 0, stream, p);
+        else if (!ta && !tb) ATHENA_LAUNCH((gemm_valu_kernel<AMap, false, false>), grid, dim3(256), 0, stream, p);
+        else if (ta && !tb) ATHENA_LAUNCH((gemm_valu_kernel<AMap, true, false>), grid, dim3(256), 0, stream, p);
+        else ATHENA_LAUNCH((gemm_valu_kernel<AMap, true, true>), grid, dim3(256), 0, stream, p);
     }
     ATHENA_CHECK_LAUNCH("gemm");
     return ATHENA_OK;

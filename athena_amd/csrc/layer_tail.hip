@@ -901,16 +901,16 @@ extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena
         p.on[m] = (bf16_t*)d->next_out[m];
     }
     if (qkv && d->dff > 0)
-        hipLaunchKernelGGL((layer_tail_fwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+        ATHENA_LAUNCH((layer_tail_fwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (qkv)
-        hipLaunchKernelGGL((layer_tail_fwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+        ATHENA_LAUNCH((layer_tail_fwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (d->dff > 0)
-        hipLaunchKernelGGL(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+        ATHENA_LAUNCH(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(layer_tail_fwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+        ATHENA_LAUNCH(layer_tail_fwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     ATHENA_CHECK_LAUNCH("athena_layer_tail_fwd");
     return ATHENA_OK;
@@ -954,16 +954,16 @@ extern "C" int athena_layer_tail_bwd(const athena_layer_tail_bwd_desc* d, athena
     p.add = (const bf16_t*)d->add_dqkv;
     for (int m = 0; m < 3; ++m) p.aw[m] = (const bf16_t*)d->add_w[m];
     if (add && d->dff > 0)
-        hipLaunchKernelGGL((layer_tail_bwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+        ATHENA_LAUNCH((layer_tail_bwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (add)
-        hipLaunchKernelGGL((layer_tail_bwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
+        ATHENA_LAUNCH((layer_tail_bwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
                            dim3(LT_THREADS), 0, (hipStream_t)stream, p);
     else if (d->dff > 0)
-        hipLaunchKernelGGL(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+        ATHENA_LAUNCH(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(layer_tail_bwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
+        ATHENA_LAUNCH(layer_tail_bwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
                            (hipStream_t)stream, p);
     ATHENA_CHECK_LAUNCH("athena_layer_tail_bwd");
     return ATHENA_OK;

@@ -1417,7 +1417,7 @@ static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, 
                                const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
                                float* loss, int32_t* argmax, float gscale, TG* grad, hipStream_t s) {
 #define CTC_ROW(G, NR)                                                                                         \
-    hipLaunchKernelGGL((ctc_row_kernel<T, TG, G, NR>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len, \
+    ATHENA_LAUNCH((ctc_row_kernel<T, TG, G, NR>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len, \
                        logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first, gscale, grad)
     if (grad) {
         if (ldl <= 5 * 1024) CTC_ROW(true, 5);
@@ -1428,10 +1428,10 @@ static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, 
     }
 #undef CTC_ROW
 #define CTC_LAT_POST(N)                                                                                          \
-    hipLaunchKernelGGL((ctc_lattice_kernel<T, TG, N>), dim3(B), dim3(256), 0, s, ws.emis, labels, label_len,     \
+    ATHENA_LAUNCH((ctc_lattice_kernel<T, TG, N>), dim3(B), dim3(256), 0, s, ws.emis, labels, label_len,     \
                        logit_len, Tn, U, ws.alpha, ws.beta, ws.ll, logits, ldl, V, blank, ws.Up, ws.lse, ws.occ, \
                        ws.first, ws.flags, loss, gscale, grad);                                                  \
-    hipLaunchKernelGGL((ctc_post_kernel<TG, N>), dim3(B * ((Tn + CTC_POST_ROWS(N) - 1) / CTC_POST_ROWS(N))), dim3(64 * CTC_POST_ROWS(N)), 0, s, labels, label_len, logit_len, \
+    ATHENA_LAUNCH((ctc_post_kernel<TG, N>), dim3(B * ((Tn + CTC_POST_ROWS(N) - 1) / CTC_POST_ROWS(N))), dim3(64 * CTC_POST_ROWS(N)), 0, s, labels, label_len, logit_len, \
                        Tn, V, U, blank, ldl, ws.Up, (Tn + CTC_POST_ROWS(N) - 1) / CTC_POST_ROWS(N), ws.nrm, ws.emis, ws.alpha, ws.beta, ws.occ, ws.first, \
                        ws.ll, ws.flags, loss, gscale, grad)
     switch (ctc_launch_r(2 * U + 1)) {
@@ -1517,10 +1517,10 @@ extern "C" int athena_rescale_unless(void* x, long n, int dtype, const float* up
     // with the grid
     const int grid = (int)((n4 + 255) / 256 < 128 ? (n4 + 255) / 256 : 128);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(rescale_unless_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n4,
+        ATHENA_LAUNCH(rescale_unless_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, n4,
                            upstream, expected);
     else
-        hipLaunchKernelGGL(rescale_unless_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, n4,
+        ATHENA_LAUNCH(rescale_unless_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, n4,
                            upstream, expected);
     ATHENA_CHECK_LAUNCH("athena_rescale_unless");
     return ATHENA_OK;
@@ -1591,7 +1591,7 @@ extern "C" int athena_ctc_loss_bwd(const void* logits, int logits_dtype, int ldl
     int chunk = (ldl + 1023) / 1024 * 1024;
     if (chunk > CTC_OCC_CHUNK) chunk = CTC_OCC_CHUNK;
 #define CTC_GRAD(TL, TG)                                                                                          \
-    hipLaunchKernelGGL((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), chunk * sizeof(float), s,                \
+    ATHENA_LAUNCH((ctc_grad_kernel<TL, TG>), dim3(grid), dim3(256), chunk * sizeof(float), s,                \
                        (const TL*)logits, ldl, labels, label_len, logit_len, T, V, U, blank, ws.Up, ws.lse,       \
                        ws.occ, ws.flags, grad_scale, host_scale, (TG*)grad, rows, chunk)
     if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CTC_GRAD(float, float);
@@ -1669,9 +1669,9 @@ extern "C" int athena_ce_loss_fwd(const void* logits, int logits_dtype, int ldl,
     ATHENA_REQUIRE(ldl % 4 == 0 && athena_aligned16(logits), ATHENA_E_ALIGN, "athena_ce_loss_fwd: ldl %% 4 and 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
     if (logits_dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, ldl, targets, V, label_smoothing, row_loss, lse);
+        ATHENA_LAUNCH(ce_fwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, ldl, targets, V, label_smoothing, row_loss, lse);
     else if (logits_dtype == ATHENA_F32)
-        hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)logits, ldl, targets, V, label_smoothing, row_loss, lse);
+        ATHENA_LAUNCH(ce_fwd_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)logits, ldl, targets, V, label_smoothing, row_loss, lse);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_ce_loss_fwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_ce_loss_fwd");
@@ -1684,7 +1684,7 @@ extern "C" int athena_ce_loss_bwd(const void* logits, int logits_dtype, int ldl,
     ATHENA_REQUIRE(logits && targets && lse && grad, ATHENA_E_SHAPE, "athena_ce_loss_bwd: null operand");
     ATHENA_REQUIRE(rows > 0 && V > 1 && ldl >= V, ATHENA_E_SHAPE, "athena_ce_loss_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-#define CE_BWD(TL, TG) hipLaunchKernelGGL((ce_bwd_kernel<TL, TG>), dim3(rows), dim3(256), 0, s, (const TL*)logits, ldl, targets, V, label_smoothing, lse, grad_scale, host_scale, (TG*)grad)
+#define CE_BWD(TL, TG) ATHENA_LAUNCH((ce_bwd_kernel<TL, TG>), dim3(rows), dim3(256), 0, s, (const TL*)logits, ldl, targets, V, label_smoothing, lse, grad_scale, host_scale, (TG*)grad)
     if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_F32) CE_BWD(float, float);
     else if (logits_dtype == ATHENA_F32 && grad_dtype == ATHENA_BF16) CE_BWD(float, bf16_t);
     else if (logits_dtype == ATHENA_BF16 && grad_dtype == ATHENA_BF16) CE_BWD(bf16_t, bf16_t);
@@ -1731,9 +1731,9 @@ extern "C" int athena_argmax_rows(const void* logits, int dtype, int ldl, int ro
     ATHENA_REQUIRE(logits && out && rows > 0 && V > 0 && ldl >= V, ATHENA_E_SHAPE, "athena_argmax_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(argmax_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, ldl, V, out);
+        ATHENA_LAUNCH(argmax_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, (const bf16_t*)logits, ldl, V, out);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(argmax_rows_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)logits, ldl, V, out);
+        ATHENA_LAUNCH(argmax_rows_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)logits, ldl, V, out);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_argmax_rows: dtype");
     ATHENA_CHECK_LAUNCH("athena_argmax_rows");
@@ -1800,7 +1800,7 @@ extern "C" int athena_mpc_loss_fwd(const float* logits, int ldl, const float* ta
     ATHENA_REQUIRE(logits && target && masked_input && logit_len && row_loss, ATHENA_E_SHAPE, "athena_mpc_loss_fwd: null operand");
     ATHENA_REQUIRE(B > 0 && Tp > 0 && N > 0 && ldl >= N && (long)B * Tp < (1L << 31), ATHENA_E_SHAPE,
                    "athena_mpc_loss_fwd: bad shape B=%d Tp=%d N=%d ldl=%d", B, Tp, N, ldl);
-    hipLaunchKernelGGL(mpc_loss_fwd_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+    ATHENA_LAUNCH(mpc_loss_fwd_kernel, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
                        masked_input, logit_len, Tp, N, row_loss);
     ATHENA_CHECK_LAUNCH("athena_mpc_loss_fwd");
     return ATHENA_OK;
@@ -1813,10 +1813,10 @@ extern "C" int athena_mpc_loss_bwd(const float* logits, int ldl, const float* ta
     ATHENA_REQUIRE(B > 0 && Tp > 0 && N > 0 && ldl >= N && (long)B * Tp < (1L << 31), ATHENA_E_SHAPE,
                    "athena_mpc_loss_bwd: bad shape B=%d Tp=%d N=%d ldl=%d", B, Tp, N, ldl);
     if (grad_dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(mpc_loss_bwd_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+        ATHENA_LAUNCH(mpc_loss_bwd_kernel<bf16_t>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
                            masked_input, logit_len, Tp, N, grad_scale, host_scale, (bf16_t*)grad);
     else if (grad_dtype == ATHENA_F32)
-        hipLaunchKernelGGL(mpc_loss_bwd_kernel<float>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
+        ATHENA_LAUNCH(mpc_loss_bwd_kernel<float>, dim3(B * Tp), dim3(256), 0, (hipStream_t)stream, logits, ldl, target,
                            masked_input, logit_len, Tp, N, grad_scale, host_scale, (float*)grad);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_mpc_loss_bwd: grad dtype");
@@ -1827,7 +1827,7 @@ extern "C" int athena_mpc_loss_bwd(const float* logits, int ldl, const float* ta
 extern "C" int athena_group_sum(const float* x, int ngroups, int group, float scale, float* out,
                                 athena_stream_t stream) {
     ATHENA_REQUIRE(x && out && ngroups > 0 && group > 0, ATHENA_E_SHAPE, "athena_group_sum: bad arguments");
-    hipLaunchKernelGGL(group_sum_kernel, dim3(ngroups), dim3(256), 0, (hipStream_t)stream, x, group, scale, out);
+    ATHENA_LAUNCH(group_sum_kernel, dim3(ngroups), dim3(256), 0, (hipStream_t)stream, x, group, scale, out);
     ATHENA_CHECK_LAUNCH("athena_group_sum");
     return ATHENA_OK;
 }

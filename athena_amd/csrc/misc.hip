@@ -102,9 +102,9 @@ extern "C" int athena_conv3x3s2_small_cin_fwd(const float* in, const float* w_hw
     const long npix = (long)B * Ho * Wo;
     dim3 grid((unsigned)((npix + SC_PIX_PER_BLOCK - 1) / SC_PIX_PER_BLOCK), (cpr + cpb - 1) / cpb);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(conv_small_cin_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, in, w_hwio, (bf16_t*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
+        ATHENA_LAUNCH(conv_small_cin_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, in, w_hwio, (bf16_t*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(conv_small_cin_fwd_kernel<float>, grid, dim3(256), 0, s, in, w_hwio, (float*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
+        ATHENA_LAUNCH(conv_small_cin_fwd_kernel<float>, grid, dim3(256), 0, s, in, w_hwio, (float*)out, B, H, W, Cin, Cout, Ho, Wo, ph, pw, colstats);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_conv3x3s2_small_cin_fwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_conv3x3s2_small_cin_fwd");
@@ -190,9 +190,9 @@ extern "C" int athena_conv3x3s2_small_cin_wgrad(const float* in, const void* dou
     const long npix = (long)B * Ho * Wo;
     dim3 grid((unsigned)((npix + SW_PIX_PER_BLOCK - 1) / SW_PIX_PER_BLOCK), (cpr + cpb - 1) / cpb, Cin);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(conv_small_cin_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, in, (const bf16_t*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
+        ATHENA_LAUNCH(conv_small_cin_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, in, (const bf16_t*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(conv_small_cin_wgrad_kernel<float>, grid, dim3(256), 0, s, in, (const float*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
+        ATHENA_LAUNCH(conv_small_cin_wgrad_kernel<float>, grid, dim3(256), 0, s, in, (const float*)dout, dw_hwio, B, H, W, Cin, Cout, Ho, Wo, ph, pw);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_conv3x3s2_small_cin_wgrad: dtype");
     ATHENA_CHECK_LAUNCH("athena_conv3x3s2_small_cin_wgrad");
@@ -227,9 +227,9 @@ extern "C" int athena_add_pe_dropout(const void* x, const float* pe, int B, int 
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(add_pe_dropout_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
+        ATHENA_LAUNCH(add_pe_dropout_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(add_pe_dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (float*)y);
+        ATHENA_LAUNCH(add_pe_dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, pe, n, T, d, xscale, th, ds, rng_state, rng_site, (float*)y);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_add_pe_dropout: dtype");
     ATHENA_CHECK_LAUNCH("athena_add_pe_dropout");
@@ -264,9 +264,9 @@ extern "C" int athena_dropout_bwd(const void* dy, long n, int dtype, float xscal
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, n, xscale, th, ds, rng_state, rng_site, (const bf16_t*)relu6_out, (bf16_t*)dx);
+        ATHENA_LAUNCH(dropout_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, n, xscale, th, ds, rng_state, rng_site, (const bf16_t*)relu6_out, (bf16_t*)dx);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, n, xscale, th, ds, rng_state, rng_site, (const float*)relu6_out, (float*)dx);
+        ATHENA_LAUNCH(dropout_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, n, xscale, th, ds, rng_state, rng_site, (const float*)relu6_out, (float*)dx);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_dropout_bwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_dropout_bwd");
@@ -322,9 +322,9 @@ extern "C" int athena_embed_fwd(const float* table, const int32_t* ids, const fl
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
+        ATHENA_LAUNCH(embed_fwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (bf16_t*)y);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (float*)y);
+        ATHENA_LAUNCH(embed_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, table, ids, pe, n, L, d, V, xscale, th, ds, rng_state, rng_site, (float*)y);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_fwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_embed_fwd");
@@ -343,9 +343,9 @@ extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        ATHENA_LAUNCH(embed_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        ATHENA_LAUNCH(embed_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_bwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_embed_bwd");
@@ -394,7 +394,7 @@ extern "C" int athena_copy_many(const void* const* src, void* const* dst, const 
     long blocks = (most / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, c);
+    ATHENA_LAUNCH(copy_many_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, c);
     ATHENA_CHECK_LAUNCH("athena_copy_many");
     return ATHENA_OK;
 }
@@ -412,10 +412,10 @@ extern "C" int athena_cast(const void* src, int src_dtype, void* dst, int dst_dt
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     dim3 g((unsigned)blocks), b(256);
-    if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
-    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
-    else if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
-    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_BF16) ATHENA_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_F32) ATHENA_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == ATHENA_F32 && dst_dtype == ATHENA_F32) ATHENA_LAUNCH((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == ATHENA_BF16 && dst_dtype == ATHENA_BF16) ATHENA_LAUNCH((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
     else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_cast: dtype");
     ATHENA_CHECK_LAUNCH("athena_cast");
     return ATHENA_OK;
@@ -435,8 +435,8 @@ extern "C" int athena_axpby(float a, const void* x, float b, void* y, long n, in
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == ATHENA_BF16) hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const bf16_t*)x, b, (bf16_t*)y, n);
-    else if (dtype == ATHENA_F32) hipLaunchKernelGGL(axpby_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)x, b, (float*)y, n);
+    if (dtype == ATHENA_BF16) ATHENA_LAUNCH(axpby_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const bf16_t*)x, b, (bf16_t*)y, n);
+    else if (dtype == ATHENA_F32) ATHENA_LAUNCH(axpby_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a, (const float*)x, b, (float*)y, n);
     else ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_axpby: dtype");
     ATHENA_CHECK_LAUNCH("athena_axpby");
     return ATHENA_OK;
@@ -474,7 +474,7 @@ extern "C" int athena_prepare_labels(const int32_t* labels, const int32_t* label
     ATHENA_REQUIRE(labels && label_len && input_len && y0 && tgt && y_mask && logit_len && x_mask, ATHENA_E_SHAPE,
                    "athena_prepare_labels: null operand");
     ATHENA_REQUIRE(B > 0 && U > 0 && Tp > 0, ATHENA_E_SHAPE, "athena_prepare_labels: bad shape B=%d U=%d T'=%d", B, U, Tp);
-    hipLaunchKernelGGL(prepare_labels_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, labels, label_len, input_len, U,
+    ATHENA_LAUNCH(prepare_labels_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, labels, label_len, input_len, U,
                        Tp, sos, eos, y0, tgt, y_mask, logit_len, x_mask);
     ATHENA_CHECK_LAUNCH("athena_prepare_labels");
     return ATHENA_OK;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void ln_fold_batched_kernel(const LnFoldItem* 
 extern "C" int athena_ln_fold_batched(const athena_ln_fold_item* items, int count, int max_d,
                                       athena_stream_t stream) {
     ATHENA_REQUIRE(items && count > 0 && count <= 65535 && max_d > 0, ATHENA_E_SHAPE, "athena_ln_fold_batched: bad arguments");
-    hipLaunchKernelGGL(ln_fold_batched_kernel, dim3((2 * max_d + 15) / 16, count), dim3(256), 0, (hipStream_t)stream,
+    ATHENA_LAUNCH(ln_fold_batched_kernel, dim3((2 * max_d + 15) / 16, count), dim3(256), 0, (hipStream_t)stream,
                        (const LnFoldItem*)items);
     ATHENA_CHECK_LAUNCH("athena_ln_fold_batched");
     return ATHENA_OK;
@@ -452,11 +452,11 @@ extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const floa
         const int G = ln_group(d);
         dim3 vgrid((rows + 256 / G - 1) / (256 / G));
         if (dtype == ATHENA_BF16)
-            hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<bf16_t>, vgrid, dim3(256), 0, (hipStream_t)stream,
+            ATHENA_LAUNCH(add_layernorm_fwd_vec_kernel<bf16_t>, vgrid, dim3(256), 0, (hipStream_t)stream,
                                (const bf16_t*)a, (const bf16_t*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
                                rng_site, (bf16_t*)z, (bf16_t*)y, mean, rstd);
         else
-            hipLaunchKernelGGL(add_layernorm_fwd_vec_kernel<float>, vgrid, dim3(256), 0, (hipStream_t)stream,
+            ATHENA_LAUNCH(add_layernorm_fwd_vec_kernel<float>, vgrid, dim3(256), 0, (hipStream_t)stream,
                                (const float*)a, (const float*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
                                rng_site, (float*)z, (float*)y, mean, rstd);
         ATHENA_CHECK_LAUNCH("add_layernorm_fwd");
@@ -464,11 +464,11 @@ extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const floa
     }
     dim3 grid((rows + 3) / 4);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+        ATHENA_LAUNCH(add_layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                            (const bf16_t*)b, gamma, beta, eps, rows, d, th, ds, rng_state, rng_site, (bf16_t*)z,
                            (bf16_t*)y, mean, rstd);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(add_layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a,
+        ATHENA_LAUNCH(add_layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)a,
                            (const float*)b, gamma, beta, eps, rows, d, th, ds, rng_state, rng_site, (float*)z,
                            (float*)y, mean, rstd);
     else
@@ -495,7 +495,7 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
                            ATHENA_E_LAUNCH, "add_layernorm_bwd: memset failed");
         }
 #define LNV_BWD(GG)                                                                                                  \
-    hipLaunchKernelGGL((add_layernorm_bwd_vec_kernel<T, GG>), dim3(nblk), dim3(256), 0, stream, (const T*)dy,      \
+    ATHENA_LAUNCH((add_layernorm_bwd_vec_kernel<T, GG>), dim3(nblk), dim3(256), 0, stream, (const T*)dy,      \
                        (const T*)z, mean, rstd, gamma, rows, d, th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, \
                        dbeta, slabs)
         switch (ln_group(d)) {
@@ -509,7 +509,7 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
         }
 #undef LNV_BWD
         if (slabs && dgamma)
-            hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, stream, (const float*)slabs, nblk, d,
+            ATHENA_LAUNCH(ln_fold_kernel, dim3((2 * d + 15) / 16), dim3(256), 0, stream, (const float*)slabs, nblk, d,
                                dgamma, dbeta);
         ATHENA_CHECK_LAUNCH("add_layernorm_bwd");
         return ATHENA_OK;
@@ -524,7 +524,7 @@ static int launch_ln_bwd(const void* dy, const void* z, const float* mean, const
     }
     dim3 grid((rows + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK);
 #define LN_BWD_CASE(V)                                                                                          \
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, V>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)z, \
+    ATHENA_LAUNCH((add_layernorm_bwd_kernel<T, V>), grid, dim3(256), 0, stream, (const T*)dy, (const T*)z, \
                        mean, rstd, gamma, rows, d, th, ds, rng_state, site, acc, (T*)da, (T*)db, dgamma, dbeta)
     if (d <= 64 * 4) LN_BWD_CASE(4);
     else if (d <= 64 * 8) LN_BWD_CASE(8);
@@ -619,9 +619,9 @@ extern "C" int athena_colsum(const void* X, int dtype, int M, int N, int ld, flo
     // 256 % cpb may be non-zero: the surplus threads idle (slot >= slots)
     dim3 grid((M + CS_ROWS_PER_BLOCK - 1) / CS_ROWS_PER_BLOCK, (nchunk + cpb - 1) / cpb);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, M, N, ld, out);
+        ATHENA_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, M, N, ld, out);
     else if (dtype == ATHENA_F32)
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, M, N, ld, out);
+        ATHENA_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, M, N, ld, out);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_colsum: dtype");
     ATHENA_CHECK_LAUNCH("athena_colsum");
@@ -650,7 +650,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long rows, 
 extern "C" int athena_bn_finalize(const double* colstats, long rows, int C, float eps, float momentum,
                                   float* mean_rstd, float* moving_mean, float* moving_var, athena_stream_t stream) {
     ATHENA_REQUIRE(colstats && mean_rstd && rows > 0 && C > 0, ATHENA_E_SHAPE, "athena_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, colstats, rows, C,
+    ATHENA_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, colstats, rows, C,
                        eps, momentum, mean_rstd, moving_mean, moving_var);
     ATHENA_CHECK_LAUNCH("athena_bn_finalize");
     return ATHENA_OK;
@@ -728,7 +728,7 @@ static int bn_apply_common(const void* x, const float* s0, const float* s1, cons
     long blocks = (nchunks + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     dim3 grid((unsigned)blocks);
-#define BN_APPLY(T, I, R) hipLaunchKernelGGL((bn_relu6_apply_kernel<T, I, R>), grid, dim3(256), 0, stream, (const T*)x, s0, s1, gamma, beta, eps, nchunks, C, (T*)y)
+#define BN_APPLY(T, I, R) ATHENA_LAUNCH((bn_relu6_apply_kernel<T, I, R>), grid, dim3(256), 0, stream, (const T*)x, s0, s1, gamma, beta, eps, nchunks, C, (T*)y)
 #define BN_APPLY_R(T, I) do { if (relu6) BN_APPLY(T, I, true); else BN_APPLY(T, I, false); } while (0)
     if (dtype == ATHENA_BF16) { if (infer) BN_APPLY_R(bf16_t, true); else BN_APPLY_R(bf16_t, false); }
     else if (dtype == ATHENA_F32) { if (infer) BN_APPLY_R(float, true); else BN_APPLY_R(float, false); }
@@ -969,11 +969,11 @@ static int bn_bwd_common(const char* name, const void* dy, const void* x, const 
     const int nent = 2 * C;
 #define BN_BWD(T, R)                                                                                                    \
     do {                                                                                                                \
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), g1, dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, beta,  \
+        ATHENA_LAUNCH((bn_bwd_reduce_kernel<T, R>), g1, dim3(256), 0, s, (const T*)dy, (const T*)x, gamma, beta,  \
                            mean_rstd, rows, C, slabs);                                                                  \
-        hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab,    \
+        ATHENA_LAUNCH(bn_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(1024), 0, s, (const float*)slabs, nslab,    \
                            nent, totals);                                                                               \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy,          \
+        ATHENA_LAUNCH((bn_bwd_apply_kernel<T, R>), dim3((unsigned)blocks), dim3(256), 0, s, (const T*)dy,          \
                            (const T*)x, beta, mean_rstd, gamma, (const double*)totals, rows, C, (T*)dx, dgamma, dbeta); \
     } while (0)
     if (dtype == ATHENA_BF16) { if (relu6) BN_BWD(bf16_t, true); else BN_BWD(bf16_t, false); }
@@ -1053,9 +1053,9 @@ extern "C" int athena_bn_colstats(const void* x, long rows, int C, int dtype, do
     const int rpb = 256;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (cpr + 63) / 64);
     if (dtype == ATHENA_BF16)
-        hipLaunchKernelGGL(bn_colstats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, colstats, rpb);
+        ATHENA_LAUNCH(bn_colstats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, rows, C, colstats, rpb);
     else
-        hipLaunchKernelGGL(bn_colstats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, colstats, rpb);
+        ATHENA_LAUNCH(bn_colstats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, rows, C, colstats, rpb);
     ATHENA_CHECK_LAUNCH("athena_bn_colstats");
     return ATHENA_OK;
 }

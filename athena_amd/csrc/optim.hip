@@ -111,10 +111,10 @@ extern "C" int athena_clip_adam_step(float* params, const float* grads, float* m
     if (cfg->clip_norm > 0.f) {
         ATHENA_REQUIRE(hipMemsetAsync(norms, 0, sizeof(float) * nseg, s) == hipSuccess, ATHENA_E_LAUNCH, "athena_clip_adam_step: memset failed");
         const unsigned sblocks = (unsigned)((n + SUMSQ_CHUNK - 1) / SUMSQ_CHUNK);
-        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(sblocks), dim3(256), 0, s, grads, n, seg_offsets, nseg, cfg->grad_scale, norms);
+        ATHENA_LAUNCH(grad_sumsq_kernel, dim3(sblocks), dim3(256), 0, s, grads, n, seg_offsets, nseg, cfg->grad_scale, norms);
     }
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, seg_offsets, nseg, norms, step, *cfg, lr_out);
-    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
+    ATHENA_LAUNCH(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, m, v, n, seg_offsets, nseg, norms, step, *cfg, lr_out);
+    ATHENA_LAUNCH(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
     ATHENA_CHECK_LAUNCH("athena_clip_adam_step");
     return ATHENA_OK;
 }
@@ -205,7 +205,7 @@ extern "C" int athena_refresh_shadows(const float* params, void* shadow, const i
                                       const int64_t* tile_prefix, long total_tiles, athena_stream_t stream) {
     ATHENA_REQUIRE(params && shadow && table && tile_prefix && nmat > 0 && total_tiles > 0, ATHENA_E_SHAPE, "athena_refresh_shadows: bad arguments");
     ATHENA_REQUIRE(total_tiles < (1L << 31), ATHENA_E_SHAPE, "athena_refresh_shadows: too many tiles");
-    hipLaunchKernelGGL(refresh_shadows_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params, (bf16_t*)shadow, table, nmat, tile_prefix);
+    ATHENA_LAUNCH(refresh_shadows_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params, (bf16_t*)shadow, table, nmat, tile_prefix);
     ATHENA_CHECK_LAUNCH("athena_refresh_shadows");
     return ATHENA_OK;
 }
@@ -213,7 +213,7 @@ extern "C" int athena_refresh_shadows(const float* params, void* shadow, const i
 __global__ void advance_rng_kernel(uint64_t* st) { st[1] += 1; }
 extern "C" int athena_advance_rng(uint64_t* rng_state, athena_stream_t stream) {
     ATHENA_REQUIRE(rng_state, ATHENA_E_SHAPE, "athena_advance_rng: null");
-    hipLaunchKernelGGL(advance_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    ATHENA_LAUNCH(advance_rng_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ATHENA_CHECK_LAUNCH("athena_advance_rng");
     return ATHENA_OK;
 }

@@ -435,9 +435,9 @@ extern "C" int athena_rnn_fwd(int cell, const void* xw, const void* u, const voi
         const dim3 grid((H + RS_NU - 1) / RS_NU);
         for (int t = 0; t < T; ++t) {
             if (cell == RNN_GRU)
-                hipLaunchKernelGGL(rnn_step_fwd_mfma_kernel<RNN_GRU>, grid, dim3(512), 0, s, (const bf16_t*)xw, (const bf16_t*)u_t, H, b_rec, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
+                ATHENA_LAUNCH(rnn_step_fwd_mfma_kernel<RNN_GRU>, grid, dim3(512), 0, s, (const bf16_t*)xw, (const bf16_t*)u_t, H, b_rec, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
             else
-                hipLaunchKernelGGL(rnn_step_fwd_mfma_kernel<RNN_LSTM>, grid, dim3(512), 0, s, (const bf16_t*)xw, (const bf16_t*)u_t, H, b_rec, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
+                ATHENA_LAUNCH(rnn_step_fwd_mfma_kernel<RNN_LSTM>, grid, dim3(512), 0, s, (const bf16_t*)xw, (const bf16_t*)u_t, H, b_rec, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
         }
         ATHENA_CHECK_LAUNCH("athena_rnn_fwd");
         return ATHENA_OK;
@@ -461,14 +461,14 @@ extern "C" int athena_rnn_fwd(int cell, const void* xw, const void* u, const voi
         if (rc) return rc;
         if (cell == RNN_GRU) {
             if (dtype == ATHENA_BF16)
-                hipLaunchKernelGGL(gru_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
+                ATHENA_LAUNCH(gru_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, (bf16_t*)y, (bf16_t*)gates, (bf16_t*)rh, B, T, H, t);
             else
-                hipLaunchKernelGGL(gru_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, (float*)y, (float*)gates, (float*)rh, B, T, H, t);
+                ATHENA_LAUNCH(gru_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, (float*)y, (float*)gates, (float*)rh, B, T, H, t);
         } else {
             if (dtype == ATHENA_BF16)
-                hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, B, T, H, t);
+                ATHENA_LAUNCH(lstm_step_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)xw, hu, (bf16_t*)hs_ext, cs_ext, (bf16_t*)y, (bf16_t*)gates, B, T, H, t);
             else
-                hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, cs_ext, (float*)y, (float*)gates, B, T, H, t);
+                ATHENA_LAUNCH(lstm_step_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)xw, hu, (float*)hs_ext, cs_ext, (float*)y, (float*)gates, B, T, H, t);
         }
     }
     ATHENA_CHECK_LAUNCH("athena_rnn_fwd");
@@ -499,9 +499,9 @@ extern "C" int athena_rnn_bwd(int cell, const void* dy, const void* u, const voi
         const dim3 grid((H + RS_NU - 1) / RS_NU);
         for (int t = T - 1; t >= 0; --t) {
             if (cell == RNN_GRU)
-                hipLaunchKernelGGL(rnn_step_bwd_mfma_kernel<RNN_GRU>, grid, dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)u, G * H, (const bf16_t*)hs_ext, cs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(rnn_step_bwd_mfma_kernel<RNN_GRU>, grid, dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)u, G * H, (const bf16_t*)hs_ext, cs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
             else
-                hipLaunchKernelGGL(rnn_step_bwd_mfma_kernel<RNN_LSTM>, grid, dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)u, G * H, (const bf16_t*)hs_ext, cs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(rnn_step_bwd_mfma_kernel<RNN_LSTM>, grid, dim3(512), 0, s, (const bf16_t*)dy, (const bf16_t*)u, G * H, (const bf16_t*)hs_ext, cs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
         }
         ATHENA_CHECK_LAUNCH("athena_rnn_bwd");
         return ATHENA_OK;
@@ -522,14 +522,14 @@ extern "C" int athena_rnn_bwd(int cell, const void* dy, const void* u, const voi
     for (int t = T - 1; t >= 0; --t) {
         if (cell == RNN_GRU) {
             if (dtype == ATHENA_BF16)
-                hipLaunchKernelGGL(gru_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)hs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(gru_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)hs_ext, (const bf16_t*)gates, (const bf16_t*)rh, carry_h, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
             else
-                hipLaunchKernelGGL(gru_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)hs_ext, (const float*)gates, (const float*)rh, carry_h, (float*)dxw, (float*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(gru_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)hs_ext, (const float*)gates, (const float*)rh, carry_h, (float*)dxw, (float*)dhu_ext, B, T, H, t);
         } else {
             if (dtype == ATHENA_BF16)
-                hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, cs_ext, (const bf16_t*)gates, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(lstm_step_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, cs_ext, (const bf16_t*)gates, carry_h, carry_c, (bf16_t*)dxw, (bf16_t*)dhu_ext, B, T, H, t);
             else
-                hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, cs_ext, (const float*)gates, carry_h, carry_c, (float*)dxw, (float*)dhu_ext, B, T, H, t);
+                ATHENA_LAUNCH(lstm_step_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, cs_ext, (const float*)gates, carry_h, carry_c, (float*)dxw, (float*)dhu_ext, B, T, H, t);
         }
         if (t > 0) {
             d.A = (const char*)dhu_ext + (size_t)t * G * H * es;

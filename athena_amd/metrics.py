@@ -1,9 +1,12 @@
 """Accuracy metrics of the training step (mirror of the reference's athena/metrics.py:33-132).
 
-The arg-max over the vocabulary runs on the GPU (``athena_argmax_rows``); the greedy CTC
-collapse and the Levenshtein distance run on the host over a few thousand int32 ids, as they do
-in the reference (which pins them to /cpu:0).  Host work is deferred until ``result()`` so that
-a training step enqueues no device-to-host synchronisation.
+Everything of an update runs on the GPU inside the step: the arg-max over the vocabulary
+(``athena_argmax_rows``, or the CTC loss kernel's by-product), then the greedy CTC collapse / the cut
+at eos and the Levenshtein distance against the non-zero labels (``athena_seq_errors``, one
+workgroup per utterance), which adds (errors, labels) to a two-element device accumulator.  The host
+reads those two integers when the metric is read (every ``log_interval`` steps), so a training step
+enqueues no device-to-host synchronisation and no host-side scoring.  Hypotheses that already are
+Python lists (beam-search output) are scored on the host.
 """
 import logging
 
@@ -55,11 +58,23 @@ class Accuracy:
         self.total_count = _Sum()
         self.rank_size = rank_size
         self._pending = []
+        self._dev_counts = None      # int64 [2] on the device: (errors, labels) since the last reset
 
     def reset_states(self):
         self._drain()
         self.error_count.reset_states()
         self.total_count.reset_states()
+        if self._dev_counts is not None:
+            self._dev_counts.zero_()
+
+    def device_counts(self, device):
+        """The device accumulator the scoring kernel adds to.  It is created by the first update,
+        which is never a recorded one (a recorded step keeps adding to this same buffer)."""
+        if self._dev_counts is None or self._dev_counts.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the first update of a metric must not happen inside a graph capture")
+            self._dev_counts = torch.zeros(2, dtype=torch.int64, device=device)
+        return self._dev_counts
 
     def update_state(self, predictions, samples, logit_length=None):
         raise NotImplementedError
@@ -83,6 +98,9 @@ class Accuracy:
     def result(self):
         self._drain()
         err, tot = self.error_count.result(), self.total_count.result()
+        if self._dev_counts is not None:
+            dev = self._dev_counts.tolist()      # the one device-to-host read of the metric
+            err, tot = err + float(dev[0]), tot + float(dev[1])
         if tot == 0.0:
             return 0.0 if err > 0 else float("nan")   # x/0 = inf -> 0.0 ; 0/0 = nan
         return 1.0 - err / tot
@@ -159,14 +177,18 @@ class Seq2SeqSparseCategoricalAccuracy(CharactorAccuracy):
     def __call__(self, logits, samples, logit_length=None):
         B, L, V = logits.shape
         _, _, ld = ops._rows2d(logits)
-        pred = torch.empty(B * L, dtype=torch.int32, device=logits.device)
+        pred = torch.empty((B, L), dtype=torch.int32, device=logits.device)
         ops.argmax_rows(logits.detach(), ld, B * L, V, pred)
+        ops.seq_errors(pred, None, _labels_i32(samples["output"], logits.device), 1, int(self.eos),
+                       counts=self.device_counts(logits.device))
 
-        def score(pred_h, labels_h):
-            hyps, _ = validate_seqs(pred_h.view(B, L), self.eos)
-            self._score(hyps, labels_h.tolist())
 
-        self._pending.append(_Deferred(self, [pred, samples["output"]], score))
+def _labels_i32(labels, device):
+    """The label matrix as the scoring kernel reads it (the batches of ``prepare_samples`` already are)."""
+    t = torch.as_tensor(labels)
+    if t.device != device or t.dtype != torch.int32 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.int32).contiguous()
+    return t
 
 
 class CTCAccuracy(CharactorAccuracy):
@@ -191,18 +213,7 @@ class CTCAccuracy(CharactorAccuracy):
             pred = torch.empty(B * T, dtype=torch.int32, device=logits.device)
             ops.argmax_rows(logits.detach(), ld, B * T, V, pred)
 
-        def score(pred_h, len_h, labels_h):
-            best = pred_h.view(B, T).tolist()
-            lens = len_h.tolist()
-            hyps = []
-            for b in range(B):
-                seq, prev = [], None
-                for t in range(int(lens[b])):
-                    c = best[b][t]
-                    if c != prev and c != V - 1:
-                        seq.append(c)
-                    prev = c
-                hyps.append(seq)
-            self._score(hyps, labels_h.tolist())
-
-        self._pending.append(_Deferred(self, [pred, logit_length, samples["output"]], score))
+        lens = logit_length if (logit_length.dtype == torch.int32 and logit_length.is_contiguous()) \
+            else logit_length.to(torch.int32).contiguous()
+        ops.seq_errors(pred.view(B, T), lens, _labels_i32(samples["output"], logits.device), 0, V - 1,
+                       counts=self.device_counts(logits.device))

@@ -884,6 +884,25 @@ def argmax_rows(logits, ldl, rows, V, out):
                "athena_argmax_rows")
 
 
+def seq_errors(ids, hyp_len, labels, mode, special, counts=None, per_utt=None):
+    """Edit-distance scoring of arg-max ids [B, L] against the non-zero labels [B, U] on the device
+    (mode 0: greedy CTC collapse with blank ``special`` inside ``hyp_len`` frames; mode 1: cut at eos
+    ``special``, zeros dropped).  ``counts`` int64 [2] accumulates (errors, labels)."""
+    lib = _lib.load()
+    B, L = ids.shape
+    U = labels.shape[1]
+    for t, name in ((ids, "ids"), (labels, "labels"), (hyp_len, "hyp_len"), (per_utt, "per_utt")):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise RuntimeError("athena_amd.seq_errors: %s must be contiguous int32" % name)
+    if counts is not None and (counts.dtype != torch.int64 or counts.numel() < 2):
+        raise RuntimeError("athena_amd.seq_errors: counts must be int64 [2]")
+    if labels.shape[0] != B or (hyp_len is not None and hyp_len.numel() < B) or \
+            (per_utt is not None and per_utt.numel() < 2 * B):
+        raise RuntimeError("athena_amd.seq_errors: operand shapes do not match the batch of %d" % B)
+    _lib.check(lib.athena_seq_errors(_ptr(ids), L, _ptr(hyp_len), _ptr(labels), B, L, U, mode, special, _ptr(per_utt),
+                                     _ptr(counts), _stream()), "athena_seq_errors")
+
+
 # ------------------------------------------------------------------------------------------ optimizer
 def clip_adam_step(params, grads, m, v, seg_offsets, nseg, norms, step, cfg, lr_out):
     lib = _lib.load()

@@ -108,3 +108,26 @@ def test_one_rank_on_rccl_records_the_exchange_in_the_step_graph(tmp_path):
         if s.name.endswith(ZERO_GRAD):
             skip[s.offset:s.offset + s.numel] = True
     assert rel_err(got["params"].double()[~skip], st.params[:st.n_train].double().cpu()[~skip]) <= 1e-4
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` outside a launcher starts two ranks itself (the reference starts
+    them with ``horovodrun -np N``, README.md:243-251) and prints ONE line for the whole job.  The two
+    ranks share this box's GPU, so the sums go through gloo; the step kinds and the exchange plan are
+    the production ones."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(ATHENA_DIST_BACKEND="gloo")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny",
+                          "--steps", "3", "--warmup", "3", "--no-cpu-baseline"], env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"]
+    assert out["config"]["parallelism"] == "dp2" and out["steps"] == 3
+    assert out["value"] > 0 and out["final_loss"] == out["final_loss"]

@@ -1222,3 +1222,113 @@ def test_gemm_bf16_output_with_split_contraction(ops, M, N, K):
     # an epilogue cannot be split
     with pytest.raises(RuntimeError):
         ops.gemm(a, b, c1, M, N, K, trans_b=True, split_k=0, bias=torch.zeros(N, device=dev()))
+
+
+# ------------------------------------------------------------------------------------------ accuracy scoring
+def _ref_counts(ids, lens, labels, mode, special):
+    """Per-utterance (errors, labels) by the oracle's loops."""
+    out = []
+    for b in range(ids.shape[0]):
+        row = ids[b].tolist()
+        if mode == 0:
+            hyp, prev = [], None
+            for t in range(int(lens[b])):
+                c = row[t]
+                if c != prev and c != special:
+                    hyp.append(c)
+                prev = c
+        else:
+            hyp = []
+            for c in row:
+                if special != 0 and c == special:
+                    break
+                hyp.append(c)
+            hyp = [c for c in hyp if c != 0]
+        ref = [int(x) for x in labels[b].tolist() if int(x) != 0]
+        out.append((om.edit_distance(hyp, ref), len(ref)))
+    return out
+
+
+@pytest.mark.parametrize("B,L,U,V", [(5, 40, 7, 6), (32, 250, 32, 4233), (8, 750, 150, 50), (3, 90, 64, 9),
+                                     (4, 300, 200, 5), (2, 17, 1, 4)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_seq_errors_matches_oracle_loops(ops, B, L, U, V, mode):
+    """athena_seq_errors against the oracle's greedy decode / validate_seqs + edit distance: ragged
+    lengths, empty hypotheses, empty references, zeros inside the labels, one wave and several."""
+    g = torch.Generator().manual_seed(B * 1000 + L + U + mode)
+    special = V - 1
+    if mode == 0:
+        # runs of repeated ids so the collapse has something to merge; a quarter of the frames blank
+        ids = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32)
+        rep = torch.rand(B, L, generator=g) < 0.4
+        for t in range(1, L):
+            ids[:, t] = torch.where(rep[:, t], ids[:, t - 1], ids[:, t])
+        ids[torch.rand(B, L, generator=g) < 0.25] = special
+    else:
+        ids = torch.randint(0, V - 1, (B, L), generator=g, dtype=torch.int32)
+        for b in range(B):                              # eos somewhere (or nowhere, or first)
+            pos = int(torch.randint(0, 2 * L, (1,), generator=g))
+            if pos < L:
+                ids[b, pos:] = torch.randint(0, V, (L - pos,), generator=g, dtype=torch.int32)
+                ids[b, pos] = special
+        ids[0, 0] = special                             # empty hypothesis
+    lens = torch.randint(0, L + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = L
+    if B > 1:
+        lens[1] = 0                                     # nothing decoded
+    labels = torch.randint(0, max(V - 1, 2), (B, U), generator=g, dtype=torch.int32)   # zeros inside
+    lab_len = torch.randint(0, U + 1, (B,), generator=g)
+    for b in range(B):
+        labels[b, int(lab_len[b]):] = 0
+    if B > 2:
+        labels[2] = 0                                   # empty reference
+    want = _ref_counts(ids, lens, labels, mode, special)
+    counts = torch.tensor([5, 7], dtype=torch.int64, device=dev())
+    per = torch.full((B, 2), -1, dtype=torch.int32, device=dev())
+    ops.seq_errors(ids.to(dev()), lens.to(dev()) if mode == 0 else None, labels.to(dev()), mode, special,
+                   counts=counts, per_utt=per)
+    assert per.cpu().tolist() == [list(w) for w in want]
+    assert counts.cpu().tolist() == [5 + sum(w[0] for w in want), 7 + sum(w[1] for w in want)]
+
+
+def test_seq_errors_eos_zero_and_limits(ops):
+    ids = torch.tensor([[3, 0, 2, 0, 1]], dtype=torch.int32, device=dev())
+    labels = torch.tensor([[3, 2, 2, 0]], dtype=torch.int32, device=dev())
+    per = torch.zeros(1, 2, dtype=torch.int32, device=dev())
+    ops.seq_errors(ids, None, labels, 1, 0, per_utt=per)          # eos == 0: only the zeros go
+    assert per.cpu().tolist() == [[1, 3]]
+    with pytest.raises(RuntimeError):
+        ops.seq_errors(ids, None, torch.zeros(1, 1025, dtype=torch.int32, device=dev()), 1, 0, per_utt=per)
+
+
+def test_accuracy_metrics_score_on_the_device():
+    """CTCAccuracy / Seq2SeqSparseCategoricalAccuracy fed with logits: the counts equal the oracle's
+    (metrics.py:101-132), accumulate over updates, reset, and skip a batch whose logits are no
+    longer than the labels + 1."""
+    from athena_amd.metrics import CTCAccuracy, Seq2SeqSparseCategoricalAccuracy
+    g = torch.Generator().manual_seed(11)
+    B, T, V, U = 6, 30, 9, 5
+    m, m2 = CTCAccuracy(), Seq2SeqSparseCategoricalAccuracy(eos=V - 1)
+    err = tot = err2 = tot2 = 0.0
+    for _ in range(3):
+        logits = torch.randn(B, T, V, generator=g)
+        att = torch.randn(B, U + 1, V, generator=g)
+        labels = torch.randint(1, V - 1, (B, U), generator=g, dtype=torch.int32)
+        lens = torch.randint(1, U + 1, (B,), generator=g, dtype=torch.int32)
+        for b in range(B):
+            labels[b, int(lens[b]):] = 0
+        tl = torch.randint(U + 2, T + 1, (B,), generator=g, dtype=torch.int32)
+        samples = {"output": labels, "output_length": lens}
+        e, t = om.ctc_accuracy_counts(logits, samples, tl)
+        e2, t2 = om.seq2seq_accuracy_counts(att, samples, V - 1)
+        err, tot, err2, tot2 = err + e, tot + t, err2 + e2, tot2 + t2
+        ds = {k: v.to(dev()) for k, v in samples.items()}
+        m(logits.to(dev()), ds, tl.to(dev()))
+        m2(att.to(dev()), ds)
+    assert abs(m.result() - (1 - err / tot)) < 1e-12
+    assert abs(m2.result() - (1 - err2 / tot2)) < 1e-12
+    m.reset_states()
+    assert m.result() != m.result()
+    short = torch.randn(B, U + 1, V).to(dev())
+    m(short, ds, tl.to(dev()))                                      # skipped (metrics.py:124-125)
+    assert m.result() != m.result()
