@@ -173,22 +173,61 @@ class SpeechRecognitionDatasetBuilder(BaseDatasetBuilder):
 
     def as_dataset(self, batch_size=16, num_threads=1):
         """Batches of ``batch_size`` consecutive entries, features and labels zero-padded to the
-        longest of the batch (base.py:29-81); the incomplete last batch is dropped."""
+        longest of the batch (base.py:29-81); the incomplete last batch is dropped.  The result can
+        be iterated any number of times; every pass computes its batches as it goes, ``num_threads``
+        workers ahead of the consumer (the reference: a generator with padded_batch and prefetch)."""
         if len(self) == 0:
             raise ValueError("num samples is empty")
+        return _BatchStream(self, batch_size, num_threads)
+
+    def make_batch(self, first, batch_size):
+        """Entries first .. first + batch_size - 1 as one zero-padded batch."""
         dim, nc = self.audio_featurizer.dim, self.audio_featurizer.num_channels
-        out = []
-        for b in range(len(self) // batch_size):
-            items = [self[i] for i in range(b * batch_size, (b + 1) * batch_size)]
-            T = max(it["input_length"] for it in items)
-            U = max(it["output_length"] for it in items)
-            x = np.zeros((batch_size, T, dim, nc), dtype=np.float32)
-            y = np.zeros((batch_size, U), dtype=np.int32)
-            for k, it in enumerate(items):
-                x[k, :it["input_length"]] = it["input"]
-                y[k, :it["output_length"]] = it["output"]
-            out.append({"input": torch.from_numpy(x),
-                        "input_length": torch.tensor([it["input_length"] for it in items], dtype=torch.int32),
-                        "output": torch.from_numpy(y),
-                        "output_length": torch.tensor([it["output_length"] for it in items], dtype=torch.int32)})
-        return out
+        items = [self[i] for i in range(first, first + batch_size)]
+        T = max(it["input_length"] for it in items)
+        U = max(it["output_length"] for it in items)
+        x = np.zeros((batch_size, T, dim, nc), dtype=np.float32)
+        y = np.zeros((batch_size, U), dtype=np.int32)
+        for k, it in enumerate(items):
+            x[k, :it["input_length"]] = it["input"]
+            y[k, :it["output_length"]] = it["output"]
+        return {"input": torch.from_numpy(x),
+                "input_length": torch.tensor([it["input_length"] for it in items], dtype=torch.int32),
+                "output": torch.from_numpy(y),
+                "output_length": torch.tensor([it["output_length"] for it in items], dtype=torch.int32)}
+
+
+class _BatchStream:
+    """The batches of one epoch, made on demand.  A pass over it holds at most ``depth`` finished
+    batches: worker threads (feature extraction spends its time in numpy, which releases the
+    interpreter lock) fill a bounded window in batch order, the consumer takes them in that order.
+    The entry list is read when a pass starts, so a ``batch_wise_shuffle`` between epochs is seen."""
+
+    def __init__(self, builder, batch_size, num_threads=1, depth=None):
+        self.builder, self.batch_size = builder, int(batch_size)
+        self.workers = max(int(num_threads or 1), 1)
+        self.depth = int(depth) if depth else 2 * self.workers
+
+    def __len__(self):
+        return len(self.builder) // self.batch_size
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        n, bs, make = len(self), self.batch_size, self.builder.make_batch
+        if self.workers == 1 and self.depth <= 1:
+            for b in range(n):
+                yield make(b * bs, bs)
+            return
+        pool = ThreadPoolExecutor(max_workers=self.workers)
+        window, nxt = deque(), 0
+        try:
+            while nxt < n or window:
+                while nxt < n and len(window) < self.depth:
+                    window.append(pool.submit(make, nxt * bs, bs))
+                    nxt += 1
+                yield window.popleft().result()
+        finally:
+            for f in window:
+                f.cancel()
+            pool.shutdown(wait=True)

@@ -27,12 +27,17 @@ class _CTCLossFn(torch.autograd.Function):
     """``upstream`` (a host float or None) is the factor the caller expects this loss to receive in the
     backward pass -- the weight of the CTC term in the total loss.  With it the forward pass leaves the
     gradient too, in the same pass over the logits (athena_ctc_loss_fwd_bwd), and the backward pass only
-    corrects it on the device should the factor that arrives differ."""
+    corrects it on the device should the factor that arrives differ.  ``exact`` says that the caller
+    is a model class of this package whose total loss carries this term with exactly that factor: only
+    then, and only inside a solver step (whose root gradient is one), the comparison is left out.
+    The gradient left by the forward pass is handed out once; a further backward pass over a retained
+    graph recomputes it from the posteriors in the workspace."""
 
     @staticmethod
-    def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False, upstream=None):
+    def forward(ctx, logits, labels, label_len, logit_len, blank, bf16_grad=False, upstream=None, exact=False):
         B, T, V = logits.shape
         ctx.bf16_grad = bf16_grad
+        ctx.exact = bool(exact)
         # no zero tensor for the gradient of the arg-max output (the engine would fill one per step)
         ctx.set_materialize_grads(False)
         U = labels.shape[1]
@@ -64,23 +69,23 @@ class _CTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout, _gbest=None):
         if gout is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         src, ldl, labels, label_len, logit_len, ws = ctx.saved
         B, T, V, U, blank = ctx.dims
         gs = gout.to(torch.float32).reshape(1).contiguous()
         if ctx.grad is not None:
-            grad = ctx.grad
-            # inside a solver step the factor that arrives is the one the model announced; anywhere
-            # else it is compared on the device and the gradient corrected if it differs
-            if not ops.root_gradient_is_one():
+            grad, ctx.grad = ctx.grad, None          # handed out once
+            # the factor that arrives is compared on the device with the one announced and the gradient
+            # corrected if they differ (a no-op launch when they agree)
+            if not (ctx.exact and ops.root_gradient_is_one()):
                 ops.rescale_unless(grad, gs, ctx.upstream)
         else:
             gdt = torch.bfloat16 if ctx.bf16_grad else torch.float32
             grad = torch.empty((B, T, ldl), dtype=gdt, device=src.device)
             ops.ctc_loss_bwd(src, ldl, labels, label_len, logit_len, B, T, V, U, blank, gs, 1.0 / B, grad, ws)
         if ctx.bf16_grad:
-            return ops.bf16_grad_standin((B, T, V), grad), None, None, None, None, None, None
-        return grad[..., :V], None, None, None, None, None, None
+            return ops.bf16_grad_standin((B, T, V), grad), None, None, None, None, None, None, None
+        return grad[..., :V], None, None, None, None, None, None, None
 
 
 class CTCLoss:
@@ -96,14 +101,15 @@ class CTCLoss:
         self.need_logit_length = True
         self.takes_upstream = True
 
-    def __call__(self, logits, samples, logit_length=None, upstream=None):
+    def __call__(self, logits, samples, logit_length=None, upstream=None, exact=False):
         """``upstream``: the weight this loss will carry in the total loss, if the caller knows it (a
-        host float); the gradient is then produced together with the loss."""
+        host float); the gradient is then produced together with the loss.  ``exact``: the caller
+        vouches that the total loss of a solver step carries this term with exactly that weight."""
         assert logit_length is not None
         V = logits.shape[-1]
         blank = self.blank_index + V if self.blank_index < 0 else self.blank_index
         loss, best = _CTCLossFn.apply(logits, samples["output"], samples["output_length"], logit_length, blank,
-                                      ops.bf16_grad_wanted(logits), upstream)
+                                      ops.bf16_grad_wanted(logits), upstream, exact)
         # CTCAccuracy on the same logits and lengths picks this up instead of a second pass over them
         logits._athena_ctc_argmax = (best, logits._version, logit_length)
         return loss

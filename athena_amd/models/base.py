@@ -28,7 +28,7 @@ class BaseModel(nn.Module):
             logit_length = self.compute_logit_length(samples)
             if getattr(self.loss_function, "takes_upstream", False):
                 # this loss is the whole objective: its gradient arrives with factor 1
-                loss = self.loss_function(outputs, samples, logit_length, upstream=1.0)
+                loss = self.loss_function(outputs, samples, logit_length, upstream=1.0, exact=True)
             else:
                 loss = self.loss_function(outputs, samples, logit_length)
         if self.metric is None:

@@ -76,7 +76,8 @@ class MtlTransformerCtc(BaseModel):
         # the CTC term enters the total with weight 1 - mtl_weight: that is the factor its gradient
         # will arrive with, so the loss can leave the gradient in the same pass over the logits
         ctc_weight = 1.0 - float(self.hparams.mtl_weight)
-        extra_loss = self.loss_function(ctc_logits, samples, logit_length, upstream=ctc_weight if ctc_weight > 0 else None)
+        extra_loss = self.loss_function(ctc_logits, samples, logit_length, upstream=ctc_weight if ctc_weight > 0 else None,
+                                        exact=True)
         self.metric(ctc_logits, samples, logit_length)
         main_loss, metrics = self.model.get_loss(attention_logits, samples, training=training)
         mtl_weight = self.hparams.mtl_weight

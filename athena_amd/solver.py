@@ -530,13 +530,23 @@ class HorovodSolver(BaseSolver):
         self._rccl, self._side, self._plan = None, None, None
         if (self.world_size > 1 or self._force_exchange) and dist.is_initialized() and dist.get_backend() == "nccl" \
                 and os.environ.get("ATHENA_DP_OWN_COMM", "1") != "0":
+            from .utils.rccl import Communicator, all_ranks_agree
+            comm, why = None, None
             try:
-                from .utils.rccl import Communicator
-                comm = Communicator()
+                comm = Communicator()          # collective: raises on every rank or on none
                 comm.self_test()
-                self._rccl = comm
             except Exception as e:      # noqa: BLE001 -- any failure means: collectives through torch.distributed
-                logging.warning("own RCCL communicator unavailable (%s): gradient exchange between graphs", e)
+                why = e
+            # which communicator carries the exchange is decided ONCE, here, and for all ranks together:
+            # a rank whose self-test failed alone would otherwise issue its collectives on the process
+            # group while the others issue theirs on their own communicators, and the job would hang
+            if all_ranks_agree(why is None):
+                self._rccl = comm
+            else:
+                if comm is not None:
+                    comm.close()
+                logging.warning("own RCCL communicator unavailable (%s): gradient exchange between graphs",
+                                why or "failed on another rank")
 
     @staticmethod
     def initialize_devices(solver_gpus=None):
@@ -617,6 +627,10 @@ class HorovodSolver(BaseSolver):
         # torch.distributed; what remains when the own communicator cannot be had), "split" (two graphs
         # around one exchange; also ATHENA_DP_PIPELINE=0).  With a single rank and no forced exchange
         # the plain single graph is recorded.
+        # Ranks record at different times (their batch shapes differ), so the fallbacks below are local
+        # decisions -- and may be: every kind of step sends the slices of _exchange_plan, in that order,
+        # through _exchange_async, i.e. through the communicator chosen for all ranks in __init__.  A
+        # rank that falls back changes how ITS step is cut into graphs, never what it exchanges or where.
         dp = self.world_size > 1 or self._force_exchange
         mode = os.environ.get("ATHENA_DP_MODE", "")
         if not mode:

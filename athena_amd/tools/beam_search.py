@@ -87,7 +87,12 @@ class BeamSearchDecoder:
         if beam and hparams.ctc_weight != 0:
             dec.set_ctc_scorer(CTCPrefixScorer(eos, ctc_beam=hparams.beam_size * 2, num_classes=num_class,
                                                ctc_weight=hparams.ctc_weight))
-        if getattr(hparams, "lm_weight", 0) != 0:
+        # a language-model scorer is attached only for lm_type "ngram" / "rnn" (beam_search.py:78-94); any
+        # other lm_type -- the default "" included -- decodes without one whatever lm_weight says
+        lm_type = getattr(hparams, "lm_type", "")
+        if getattr(hparams, "lm_weight", 0) != 0 and lm_type in ("ngram", "rnn"):
+            if lm_type == "ngram" and getattr(hparams, "lm_path", None) is None:
+                raise ValueError("lm path should not be none")
             raise NotImplementedError("language-model scorers (n-gram, RNN) are not built")
         return dec
 

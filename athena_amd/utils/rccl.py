@@ -39,22 +39,52 @@ def _load():
     return lib
 
 
+def all_ranks_agree(ok):
+    """True when ``ok`` holds on every rank of the default process group (a MIN all-reduce of the flag).
+    Every rank must call it at the same point: it is how a decision taken from a local failure
+    becomes the same decision everywhere."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    on_gpu = dist.get_backend() == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 class Communicator:
-    """One RCCL communicator over the ranks of the default process group (one GPU per rank)."""
+    """One RCCL communicator over the ranks of the default process group (one GPU per rank).
+
+    Construction is collective and fails on every rank or on none: a rank on which a local step
+    fails (loading the library, drawing the unique id) still takes part in the broadcast of the id and
+    in the agreement that follows, so no rank is left waiting inside ``ncclCommInitRank`` for one that
+    gave up."""
 
     def __init__(self):
         if not dist.is_initialized():
             raise RuntimeError("athena_amd.rccl: the process group is not initialised")
-        self.lib = _load()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.comm = None
+        err = None
         uid = _UniqueId()
-        if self.rank == 0:
-            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
-        box = [bytes(bytearray(uid.internal)) if self.rank == 0 else None]
+        try:
+            self.lib = _load()
+            if self.rank == 0:
+                self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        except (OSError, RuntimeError, AttributeError) as e:
+            err = e
+        box = [bytes(bytearray(uid.internal)) if (self.rank == 0 and err is None) else None]
         dist.broadcast_object_list(box, src=0)
+        if not all_ranks_agree(err is None and box[0] is not None):
+            raise RuntimeError("athena_amd.rccl: no communicator (%s)" % (err or "another rank could not prepare one"))
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        self.comm = ctypes.c_void_p()
-        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        comm = ctypes.c_void_p()
+        rc = self.lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)
+        if rc == 0:
+            self.comm = comm
+        if not all_ranks_agree(rc == 0):
+            self.close()
+            raise RuntimeError("athena_amd.rccl: ncclCommInitRank failed%s" % (
+                ": " + self.lib.ncclGetErrorString(rc).decode() if rc != 0 else " on another rank"))
 
     def _check(self, rc, what):
         if rc != 0:

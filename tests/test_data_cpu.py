@@ -35,6 +35,38 @@ def test_vocabulary_files_of_the_reference():
     assert zh.model(3) == "丁" and zh.model([4, 2]) == "七一"
 
 
+def test_english_vocabulary_punctuation_and_table_details(tmp_path):
+    """Blank-separated table model, the callable forms, table-file details (comment lines, a table
+    without <unk> / <space>, a later line winning) and the 64 code points delete_punct removes
+    (the character class of text_featurizer.py:198-200, enumerated)."""
+    from athena_amd.data.text_featurizer import EnglishVocabulary
+    path = str(tmp_path / "words.vocab")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("# a comment\n<unk> 0\nhello 1\nworld 2\n<space> 3\n~ 4\nhello 5\n")
+    ev = EnglishVocabulary(path)
+    assert len(ev) == 6 and ev.unk_index == 0 and ev.eos_index == 4
+    assert ev.encode(" hello there world ") == [5, 0, 2] and ev.decode([5, 2, 9]) == "hello world <unk>"
+    assert ev("hello world") == [5, 2] and ev([2, 5]) == "world hello" and ev(2) == "world" and ev(77) == "<unk>"
+    assert ev.stoi[" "] == 3 and ev.itos[3] == " "                # the blank is the <space> token
+    with pytest.raises(ValueError):
+        ev(1.5)
+    bare = str(tmp_path / "bare.vocab")
+    with open(bare, "w", encoding="utf-8") as f:
+        f.write("a 1\nb 2\n")
+    v = Vocabulary(bare)
+    assert v.unk_index == 0 and " " not in v.stoi and v.encode("aXb") == [1, 0, 2] and len(v) == 3
+    assert len(Vocabulary(None)) == 1
+    eng = TextFeaturizer({"type": "eng_vocab", "model": path})
+    assert eng.unk_index == -1 and eng.model_type == "eng_vocab" and eng.encode("world hello") == [2, 5]
+    removed = ('!"#$%&()+,-./:;<>?@[]^_`|~' "\u2014\u2018\u2019\u201c\u201d\u2026\u3001\u3002\u300a\u300b\u3010\u3011"
+               "\uff01\uff03\uff04\uff05\uff06\uff07\uff08\uff09\uff0a\uff0b\uff0c\uff1a\uff1b\uff1f\uff20"
+               "\uff3b\uff3c\uff3d\uff3e\uff3f\uff40\uff5b\uff5c\uff5d\uff5e\uffe5")
+    assert len(removed) == 64
+    kept = "abc XYZ 019 '*={}\\ \u4e00\uff02"
+    assert eng.delete_punct(removed + kept + removed) == kept
+    assert all(eng.delete_punct(chr(c)) == ("" if chr(c) in removed else chr(c)) for c in range(32, 0x3100))
+
+
 def test_word_tokenizer_ranks_by_count_then_first_seen():
     t = TextFeaturizer({"type": "text", "model": None})
     t.load_model(["the cat sat", "The dog sat.", "a cat"])
@@ -99,8 +131,21 @@ def test_items_batches_shard_and_shuffle(tmp_path):
     assert item["input"].shape == (16, 8, 1) and item["input_length"] == 16
     assert item["output"] == [1, 2, 3, 3] and item["output_length"] == 4
     assert b.sample_shape["input"] == (None, 8, 1) and b.sample_signature[0]["output"][0] == (None, None)
-    batches = b.as_dataset(batch_size=3)
-    assert len(batches) == 2                                   # 7 // 3: the incomplete batch is dropped
+    stream = b.as_dataset(batch_size=3)
+    assert len(stream) == 2                                    # 7 // 3: the incomplete batch is dropped
+    assert not isinstance(stream, (list, tuple))               # batches are made as the consumer asks for them
+    batches = list(stream)
+    again = list(b.as_dataset(batch_size=3, num_threads=3))    # a pass can be repeated; workers keep the order
+    assert len(batches) == len(again) == 2
+    assert all(torch.equal(x[k], y[k]) for x, y in zip(batches, again) for k in x)
+    made = []
+    real_make = b.make_batch
+    b.make_batch = lambda first, bs: made.append(first) or real_make(first, bs)
+    it = iter(b.as_dataset(batch_size=1, num_threads=1))
+    next(it)
+    assert len(made) <= 3 < len(b)                             # a bounded window ahead, not the whole epoch
+    it.close()
+    b.make_batch = real_make
     first = batches[0]
     assert first["input"].shape == (3, 16, 8, 1) and first["output"].shape == (3, 4)
     assert first["input_length"].tolist() == [10, 13, 16] and first["output_length"].tolist() == [2, 3, 4]

@@ -112,3 +112,22 @@ def test_beam_search_finds_the_best_chain_and_beam_one_is_greedy():
     HP.beam_size = 1
     out = BeamSearchDecoder.build_decoder(HP, 4, 3, 3, step)(torch.tensor([[3]]), [torch.tensor([[3]])], 0, enc)
     assert out.tolist() == [[0, 3]]
+
+
+def test_default_lm_weight_without_lm_type_decodes_without_a_language_model():
+    """The reference attaches an LM scorer only for lm_type 'ngram' / 'rnn' (beam_search.py:78-94):
+    DecoderSolver's defaults (lm_weight 0.1, lm_type "") and recipes such as aishell/mtl_transformer.json
+    (lm_weight 0.1, no lm_type) build a decoder without one."""
+    import pytest
+    from athena_amd.solver import DecoderSolver
+    from athena_amd.utils.hparam import register_and_parse_hparams
+    hp = register_and_parse_hparams(DecoderSolver.default_config, {"decoder_type": "beam_search_decoder"})
+    assert hp.lm_weight == 0.1 and hp.lm_type == ""
+    dec = BeamSearchDecoder.build_decoder(hp, 4, 3, 3, lambda *a: None)
+    assert dec.lm_model is None and dec.scorers == []
+    hp.lm_type = "rnn"
+    with pytest.raises(NotImplementedError):
+        BeamSearchDecoder.build_decoder(hp, 4, 3, 3, lambda *a: None)
+    hp.lm_type = "ngram"
+    with pytest.raises(ValueError):
+        BeamSearchDecoder.build_decoder(hp, 4, 3, 3, lambda *a: None)

@@ -68,7 +68,10 @@ def _worker(rank, world, port, bucket_mb, ret):
     dist.all_gather(p0, model.store.params)
     ok_bcast = all(torch.equal(p0[0], t) for t in p0) and float(solver.optimizer.m[0]) == 1.0 and \
         model.store.shadows_dirty
-    ret[rank] = (ok_mean, ok_buckets, ok_bcast, len(b), scale)
+    # a decision taken from a local failure becomes everybody's: one rank saying no is a no everywhere
+    from athena_amd.utils.rccl import all_ranks_agree
+    ok_agree = all_ranks_agree(True) and not all_ranks_agree(rank != 1) and solver._rccl is None
+    ret[rank] = (ok_mean, ok_buckets, ok_bcast and ok_agree, len(b), scale)
     dist.destroy_process_group()
 
 

@@ -845,6 +845,13 @@ def test_ctc_loss_function_with_expected_upstream():
     assert grads[0][0] == grads[1][0] == grads[2][0]
     assert_close(grads[1][1], grads[0][1].double(), 1e-6, "gradient written with the loss")
     assert_close(grads[2][1], grads[0][1].double() * (1.1 / 0.3), 1e-6, "gradient corrected in the backward pass")
+    # a second backward pass over a retained graph gets a gradient of its own, not the first one
+    # scaled twice: x.grad accumulates 0.3 g + 0.7 g
+    x = torch.from_numpy(logits).float().to(dev()).requires_grad_(True)
+    loss = CTCLoss(blank_index=-1)(x, samples, tl, upstream=0.3)
+    (loss * 0.3).backward(retain_graph=True)
+    (loss * 0.7).backward()
+    assert_close(x.grad, grads[0][1].double() / 0.3, 1e-6, "two backward passes over one forward pass")
 
 
 def test_ctc_label_row_too_long_is_refused(ops):
