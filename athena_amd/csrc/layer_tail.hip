@@ -145,8 +145,14 @@ __device__ __forceinline__ void lt_tile_to_img(bf16_t* img, const LtTile& t, int
 // launch writes (7.5 KB per row of the layer, 60 MB in all) are read by LATER launches; kept in L2
 // they push out the layer's weights, which every workgroup of this launch streams from there
 // (forward tail 42.6 -> 40.5 us, backward 44.0 -> 41-43 us at 8000 rows).
-__device__ __forceinline__ void lt_store16_through(bf16_t* p, bf16x8_t v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// ``base`` is the (wave-uniform) start of the tensor, ``elem`` the element the 16 bytes start at.
+// Issued as a buffer store through the compiler's builtin, not as inline assembly: a 16-byte store
+// followed too closely by a write to its data registers needs wait states that only the compiler's
+// hazard recognizer inserts (as inline assembly this stored garbage now and then).
+typedef unsigned int lt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lt_store16_through(bf16_t* base, long elem, bf16x8_t v) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lt_u32x4, v), rsrc, (unsigned)(elem * 2), 0, 16 /* sc1 */);
 }
 
 __device__ __forceinline__ void lt_img_to_global(const bf16_t* img, bf16_t* __restrict__ dst, long ld, int col0,
@@ -160,7 +166,7 @@ __device__ __forceinline__ void lt_img_to_global(const bf16_t* img, bf16_t* __re
 #else
         if (row0 + r < rows)
 #endif
-            lt_store16_through(dst + (long)(row0 + r) * ld + col0 + (q & 31) * 8, *(const bf16x8_t*)(img + lt_img_off(r, (q & 31) * 8)));
+            lt_store16_through(dst, (long)(row0 + r) * ld + col0 + (q & 31) * 8, *(const bf16x8_t*)(img + lt_img_off(r, (q & 31) * 8)));
     }
 }
 // the four values of an image a lane owns in accumulator layout (row r, columns n .. n + 3, n % 4 == 0)

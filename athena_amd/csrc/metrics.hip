@@ -88,27 +88,43 @@ __global__ void seq_errors_kernel(const int32_t* __restrict__ ids, int ld_ids, c
         int own = j;                                       // D[0][j]
         int diag = j - 1;                                  // D[0][j-1]
         const int steps = la + lb;
-        for (int s = 2; s <= steps; ++s) {
-            int nb;
-            if (ONE_WAVE) {
-                nb = wave_shift_up(own, 0);
-            } else {
-                int* buf = xch + (s & 1) * (blockDim.x + 1);
-                buf[j] = own;
-                __syncthreads();
-                nb = buf[j - 1];
-            }
-            if (j == 1) nb = s - 1;                        // D[i][0] = i
-            const int i = s - j;
-            if (j <= lb && i >= 1 && i <= la) {
-                const int sub = diag + (hyp[i - 1] != rj ? 1 : 0);
-                own = min(min(own, nb) + 1, sub);
-            }
-            diag = nb;
-        }
         if (ONE_WAVE) {
+            // Column j meets hypothesis element s - j - 1 at step s: the element column j - 1 met one
+            // step earlier.  The hypothesis therefore travels through the lanes by the same shift as
+            // the table entries, entering at lane 0 from a register copy of 64 elements at a time
+            // (v_readlane with a uniform index); no LDS access and nothing to wait for inside a step.
+            int chunk = hyp[min((int)threadIdx.x, la - 1)];            // elements 0 .. 63
+            int hv = 0;
+            for (int s = 2; s <= steps; ++s) {
+                const int e = s - 2;                                   // the element lane 0 meets at this step
+                if (e >= 64 && (e & 63) == 0) chunk = hyp[min(e + (int)threadIdx.x, la - 1)];
+                const int head = __builtin_amdgcn_readlane(chunk, e & 63);
+                hv = wave_shift_up(hv, head);
+                int nb = wave_shift_up(own, 0);
+                if (j == 1) nb = s - 1;                                // D[i][0] = i
+                const int i = s - j;
+                if (j <= lb && i >= 1 && i <= la) {
+                    const int sub = diag + (hv != rj ? 1 : 0);
+                    own = min(min(own, nb) + 1, sub);
+                }
+                diag = nb;
+            }
             dist = __shfl(own, lb - 1, 64);                // the owner of column lb holds D[la][lb]
         } else {
+            for (int s = 2; s <= steps; ++s) {
+                int* buf = xch + (s & 1) * (blockDim.x + 1);
+                buf[j] = own;
+                const int i = s - j;
+                const int he = hyp[min(max(i - 1, 0), la - 1)];        // requested before the barrier it can wait behind
+                __syncthreads();
+                int nb = buf[j - 1];
+                if (j == 1) nb = s - 1;                                // D[i][0] = i
+                if (j <= lb && i >= 1 && i <= la) {
+                    const int sub = diag + (he != rj ? 1 : 0);
+                    own = min(min(own, nb) + 1, sub);
+                }
+                diag = nb;
+            }
             __syncthreads();
             if (j == lb) xch[0] = own;
             __syncthreads();
