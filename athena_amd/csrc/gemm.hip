@@ -2,6 +2,7 @@
 #include "gemm_big.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -26,7 +27,7 @@ static int big_tiles_mode() {
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
-extern "C" int athena_abi_version(void) { return 10; }
+extern "C" int athena_abi_version(void) { return 11; }
 
 // ---------------------------------------------------------------- per-kernel timing sessions
 // Between athena_timing_begin and athena_timing_end every launch of the library carries two events
@@ -557,7 +558,6 @@ extern "C" int athena_conv3x3s2_wgrad(const void* in, const void* dout, float* d
 // ------------------------------------------------------------------ many weight gradients, one launch
 extern "C" int athena_gemm_wgrad_plan(athena_wgrad_item* items, int count, int* total_tiles) {
     ATHENA_REQUIRE(items && count > 0 && total_tiles, ATHENA_E_SHAPE, "athena_gemm_wgrad_plan: empty table");
-    long tiles = 0;
     for (int i = 0; i < count; ++i) {
         athena_wgrad_item& it = items[i];
         ATHENA_REQUIRE(it.A && it.B && it.C && it.M > 0 && it.N > 0 && it.K > 0, ATHENA_E_SHAPE,
@@ -568,18 +568,71 @@ extern "C" int athena_gemm_wgrad_plan(athena_wgrad_item* items, int count, int* 
                        it.ldb, it.ldc, it.M, it.N);
         ATHENA_REQUIRE(athena_aligned16(it.A) && athena_aligned16(it.B), ATHENA_E_ALIGN,
                        "athena_gemm_wgrad_plan: item %d: operands must be 16-byte aligned", i);
-        it.first_tile = (int32_t)tiles;
         it.tiles_m = (it.M + GB_BM - 1) / GB_BM;
-        tiles += (long)it.tiles_m * ((it.N + GB_BN - 1) / GB_BN);
-        ATHENA_REQUIRE(tiles < (1L << 30), ATHENA_E_SHAPE, "athena_gemm_wgrad_plan: too many tiles");
     }
-    *total_tiles = (int)tiles;
+    // Placement.  A tile streams its two operand panels from memory (2 x K x 256 bf16), and the tiles
+    // of one product -- and of neighbouring products with a common operand: the q / k / v projections
+    // of a layer share their input -- read the same panel.  Workgroups are dealt to the eight XCDs
+    // round-robin (blockIdx % 8), each XCD with an L2 of its own, so the launch maps workgroup b to
+    // tile (b % 8) * per + b / 8: a contiguous range of ``per`` tiles per XCD, dispatched in step.
+    // The planner fills the eight ranges with whole groups of tiles that share an operand (they run
+    // on one XCD at about the same time and the shared panel comes out of its L2 once), longest
+    // contraction first and always into the range with the least work so far, so that the ranges
+    // finish together.  Ranges are padded to equal length; a padding tile exits at once.  Which XCD a
+    // workgroup really runs on is the hardware's business: the placement is for speed only.
+    const auto tiles_of = [](const athena_wgrad_item& it) { return (long)it.tiles_m * ((it.N + GB_BN - 1) / GB_BN); };
+    struct Group { int first, n; long cost, tiles; };
+    std::vector<Group> groups;
+    for (int i = 0; i < count; ++i) {
+        const athena_wgrad_item& it = items[i];
+        const long t = tiles_of(it);
+        if (!groups.empty()) {
+            const athena_wgrad_item& pv = items[i - 1];
+            if (pv.K == it.K && (pv.A == it.A || pv.B == it.B)) {
+                Group& g = groups.back();
+                g.n += 1; g.cost += t * it.K; g.tiles += t;
+                continue;
+            }
+        }
+        groups.push_back({i, 1, t * it.K, t});
+    }
+    std::vector<int> order(groups.size());
+    for (size_t g = 0; g < groups.size(); ++g) order[g] = (int)g;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[a].cost > groups[b].cost; });
+    long load[8] = {0}, ntile[8] = {0};
+    std::vector<int> bins[8];
+    for (int g : order) {
+        int k = 0;
+        for (int x = 1; x < 8; ++x)
+            if (load[x] < load[k]) k = x;
+        bins[k].push_back(g);
+        load[k] += groups[g].cost;
+        ntile[k] += groups[g].tiles;
+    }
+    long per = 1;
+    for (int k = 0; k < 8; ++k) per = std::max(per, ntile[k]);
+    ATHENA_REQUIRE(8 * per < (1L << 30), ATHENA_E_SHAPE, "athena_gemm_wgrad_plan: too many tiles");
+    std::vector<athena_wgrad_item> placed;
+    placed.reserve(count);
+    for (int k = 0; k < 8; ++k) {
+        long cursor = k * per;
+        for (int g : bins[k])
+            for (int i = groups[g].first; i < groups[g].first + groups[g].n; ++i) {
+                athena_wgrad_item it = items[i];
+                it.first_tile = (int32_t)cursor;
+                cursor += tiles_of(it);
+                placed.push_back(it);
+            }
+    }
+    for (int i = 0; i < count; ++i) items[i] = placed[i];      // ascending first_tile: the kernel searches it
+    *total_tiles = (int)(8 * per);
     return ATHENA_OK;
 }
 
 extern "C" int athena_gemm_wgrad_table(const athena_wgrad_item* table_dev, int count, int total_tiles,
                                        athena_stream_t stream) {
-    ATHENA_REQUIRE(table_dev && count > 0 && total_tiles > 0, ATHENA_E_SHAPE, "athena_gemm_wgrad_table: empty table");
+    ATHENA_REQUIRE(table_dev && count > 0 && total_tiles > 0 && total_tiles % 8 == 0, ATHENA_E_SHAPE,
+                   "athena_gemm_wgrad_table: empty table, or a tile count that athena_gemm_wgrad_plan did not return");
     ATHENA_LAUNCH(gemm_big_table_kernel, dim3((unsigned)total_tiles), dim3(GB_THREADS), 0, (hipStream_t)stream,
                        (const GbItem*)table_dev, count);
     ATHENA_CHECK_LAUNCH("athena_gemm_wgrad_table");

@@ -370,15 +370,19 @@ static_assert(sizeof(GbItem) == sizeof(athena_wgrad_item), "GbItem mirrors athen
 
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_table_kernel(const GbItem* __restrict__ table, int count) {
     __shared__ __attribute__((aligned(1024))) bf16_t lds[GB_LDS_ELEMS];
-    // the problem this workgroup belongs to (uniform; the table is a few KB and stays in cache)
+    // workgroup -> tile: the planner's eight ranges, one per XCD under round-robin placement
+    const int per = gridDim.x >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    // the problem this tile belongs to (uniform; the table is a few KB and stays in cache)
     int lo = 0, hi = count - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[mid].first_tile <= (int)blockIdx.x) lo = mid;
+        if (table[mid].first_tile <= tile) lo = mid;
         else hi = mid - 1;
     }
     const GbItem it = table[lo];
-    const int local = blockIdx.x - it.first_tile;
+    const int local = tile - it.first_tile;
+    if (local < 0 || local >= it.tiles_m * ((it.N + GB_BN - 1) / GB_BN)) return;      // padding of a range
     GemmProblem<PlainRows> p = {};
     p.A = it.A;
     p.B = it.B;
