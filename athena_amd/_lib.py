@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libathena_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU6, ACT_GELU, ACT_MUL_DGELU, ACT_MUL_DRELU6 = 0, 1, 2, 3, 4
+ACT_UNARY, ACT_MUL_DUNARY = 16, 32          # + k: relu elu selu leaky_relu sigmoid softplus softsign tanh relu6
 
 
 class GemmDesc(Structure):
@@ -112,6 +113,7 @@ _SIGNATURES = {
                                c_int, c_float, _P, c_int, _P, _S]),
     "athena_mha_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_float, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _S]),
+    "athena_mha_weights": (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, _S]),
     "athena_conv3x3s2_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_conv3x3s2_dgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_conv1_moments_len": (c_int64, []),

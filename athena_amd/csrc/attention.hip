@@ -378,3 +378,62 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
     ATHENA_CHECK_LAUNCH("athena_mha_bwd");
     return ATHENA_OK;
 }
+
+// ------------------------------------------------------------------ attention weights, on request
+// weights[b, h, i, :] = softmax_j(q_i . k_j * scale + mask) as a tensor in memory: what
+// MultiHeadAttention.call returns beside its output (athena/layers/attention.py:161,171).  The training
+// step never asks for it (the fused kernels above keep the probabilities on chip); this is the
+// inspection path, one workgroup per (query, head), fp32 arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void mha_weights_kernel(const T* __restrict__ q, const T* __restrict__ k, int ldq,
+                                                          int ldk, const uint8_t* __restrict__ key_mask, int causal, int h,
+                                                          int Tq, int Tk, int dk, float scale, float* __restrict__ w) {
+    __shared__ float red[32];
+    __shared__ float qs[256];
+    const int i = blockIdx.x, bh = blockIdx.y, b = bh / h, hd = bh % h;
+    const T* qr = q + ((long)b * Tq + i) * ldq + hd * dk;
+    for (int c = threadIdx.x; c < dk; c += 256) qs[c] = to_f32<T>(qr[c]);
+    __syncthreads();
+    float* wr = w + ((long)bh * Tq + i) * Tk;
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < Tk; j += 256) {
+        const T* kr = k + ((long)b * Tk + j) * ldk + hd * dk;
+        float s = 0.f;
+        for (int c = 0; c < dk; ++c) s += qs[c] * to_f32<T>(kr[c]);
+        s *= scale;
+        if (causal > 0 && j > i + causal - 1) s += -1e9f;
+        if (key_mask && key_mask[(long)b * Tk + j]) s += -1e9f;
+        wr[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max(mx, red);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < Tk; j += 256) {
+        const float e = __expf(wr[j] - mx);
+        wr[j] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    for (int j = threadIdx.x; j < Tk; j += 256) wr[j] *= inv;
+}
+
+extern "C" int athena_mha_weights(const void* q, const void* k, int ldq, int ldk, const uint8_t* key_mask, int causal,
+                                  int B, int h, int Tq, int Tk, int dk, int dtype, float scale, float* weights,
+                                  athena_stream_t stream) {
+    ATHENA_REQUIRE(q && k && weights, ATHENA_E_SHAPE, "athena_mha_weights: null operand");
+    ATHENA_REQUIRE(B > 0 && h > 0 && Tq > 0 && Tk > 0 && dk > 0 && dk <= 256 && (long)B * h <= 65535 && causal >= 0 &&
+                       ldq >= h * dk && ldk >= h * dk,
+                   ATHENA_E_SHAPE, "athena_mha_weights: bad shape B=%d h=%d Tq=%d Tk=%d dk=%d", B, h, Tq, Tk, dk);
+    const dim3 grid(Tq, B * h);
+    if (dtype == ATHENA_BF16)
+        ATHENA_LAUNCH(mha_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
+                      ldq, ldk, key_mask, causal, h, Tq, Tk, dk, scale, weights);
+    else if (dtype == ATHENA_F32)
+        ATHENA_LAUNCH(mha_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)k,
+                      ldq, ldk, key_mask, causal, h, Tq, Tk, dk, scale, weights);
+    else
+        ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_mha_weights: dtype");
+    ATHENA_CHECK_LAUNCH("athena_mha_weights");
+    return ATHENA_OK;
+}

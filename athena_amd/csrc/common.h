@@ -152,6 +152,37 @@ __device__ __forceinline__ float dgelu_tanh_f(float x) {
     return fmaf(x * sg * r, du2, sg);
 }
 
+// the table activations (tf.nn.relu / elu / selu / leaky_relu / sigmoid / softplus / softsign / tanh /
+// relu6) and their derivatives at the pre-activation
+__device__ __forceinline__ float unary_f(int k, float x) {
+    switch (k) {
+        case 0: return fmaxf(x, 0.f);
+        case 1: return x > 0.f ? x : expm1f(x);
+        case 2: return 1.0507009873554805f * (x > 0.f ? x : 1.6732632423543772f * expm1f(x));
+        case 3: return x > 0.f ? x : 0.2f * x;
+        case 4: return 1.f / (1.f + __expf(-x));
+        case 5: return x > 20.f ? x : log1pf(__expf(x));
+        case 6: return x / (1.f + fabsf(x));
+        case 7: return tanhf(x);
+        case 8: return relu6f(x);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float dunary_f(int k, float x) {
+    switch (k) {
+        case 0: return x > 0.f ? 1.f : 0.f;
+        case 1: return x > 0.f ? 1.f : __expf(x);
+        case 2: return 1.0507009873554805f * (x > 0.f ? 1.f : 1.6732632423543772f * __expf(x));
+        case 3: return x > 0.f ? 1.f : 0.2f;
+        case 4: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
+        case 5: return 1.f / (1.f + __expf(-x));
+        case 6: { const float t = 1.f + fabsf(x); return 1.f / (t * t); }
+        case 7: { const float t = tanhf(x); return 1.f - t * t; }
+        case 8: return (x > 0.f && x < 6.f) ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
 // ---------------------------------------------------------------- counter-based RNG for dropout
 // state[0] = seed, state[1] = step counter (advanced once per training step on the device)
 __device__ __forceinline__ uint64_t rng_key(const uint64_t* state, uint32_t site) {

@@ -121,7 +121,11 @@ static int gemm_validate(const athena_gemm_desc* d) {
         ATHENA_REQUIRE((d->out_dtype == ATHENA_F32 || d->split_k == 0) && d->act == ATHENA_ACT_NONE && !d->bias &&
                            !d->C_pre && d->drop_p == 0.f && !d->accumulate,
                        ATHENA_E_UNSUPPORTED, "athena_gemm: split_k needs a plain output (fp32, or bf16 with split_k = 0)");
-    if (d->act == ATHENA_ACT_MUL_DGELU || d->act == ATHENA_ACT_MUL_DRELU6)
+    ATHENA_REQUIRE((d->act >= 0 && d->act <= ATHENA_ACT_MUL_DRELU6) ||
+                       (d->act >= ATHENA_ACT_UNARY && d->act < ATHENA_ACT_UNARY + ATHENA_UNARY_COUNT) ||
+                       (d->act >= ATHENA_ACT_MUL_DUNARY && d->act < ATHENA_ACT_MUL_DUNARY + ATHENA_UNARY_COUNT),
+                   ATHENA_E_UNSUPPORTED, "athena_gemm: activation %d", d->act);
+    if (d->act == ATHENA_ACT_MUL_DGELU || d->act == ATHENA_ACT_MUL_DRELU6 || d->act >= ATHENA_ACT_MUL_DUNARY)
         ATHENA_REQUIRE(d->aux && d->ldaux >= d->N, ATHENA_E_SHAPE, "athena_gemm: backward epilogue needs aux");
     if (d->drop_p > 0.f)
         ATHENA_REQUIRE(d->rng_state && d->drop_p < 1.f, ATHENA_E_SHAPE, "athena_gemm: dropout needs rng_state and p < 1");

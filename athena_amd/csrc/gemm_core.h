@@ -50,7 +50,10 @@ __device__ __forceinline__ float epilogue_value(const Epilogue& e, long ci, long
             float y = load_as_f32(e.aux, ai, e.aux_dtype);
             v = (y > 0.f && y < 6.f) ? v : 0.f;
         } break;
-        default: break;
+        default:
+            if (e.act >= ATHENA_ACT_MUL_DUNARY) v *= dunary_f(e.act - ATHENA_ACT_MUL_DUNARY, load_as_f32(e.aux, ai, e.aux_dtype));
+            else if (e.act >= ATHENA_ACT_UNARY) v = unary_f(e.act - ATHENA_ACT_UNARY, v);
+            break;
     }
     if (e.drop_thresh) v *= dropout_mult(key, (uint64_t)ci, e.drop_thresh, e.drop_scale);
     return v;
@@ -680,7 +683,10 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
             } else if (e.act == ATHENA_ACT_GELU) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
-            } else if (e.act == ATHENA_ACT_MUL_DGELU || e.act == ATHENA_ACT_MUL_DRELU6) {
+            } else if (e.act >= ATHENA_ACT_UNARY && e.act < ATHENA_ACT_MUL_DUNARY) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = unary_f(e.act - ATHENA_ACT_UNARY, v[r]);
+            } else if (e.act == ATHENA_ACT_MUL_DGELU || e.act == ATHENA_ACT_MUL_DRELU6 || e.act >= ATHENA_ACT_MUL_DUNARY) {
                 float a[8];
                 const long ai = (long)mo * e.ldaux + n;
                 if (aux_vec && e.aux_dtype == ATHENA_BF16) {
@@ -699,6 +705,9 @@ __device__ __forceinline__ void gemm_mfma_body(const GemmProblem<AMap>& p, const
                 if (e.act == ATHENA_ACT_MUL_DGELU) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] *= dgelu_tanh_f(a[r]);
+                } else if (e.act >= ATHENA_ACT_MUL_DUNARY) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] *= dunary_f(e.act - ATHENA_ACT_MUL_DUNARY, a[r]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = (a[r] > 0.f && a[r] < 6.f) ? v[r] : 0.f;

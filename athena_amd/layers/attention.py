@@ -58,15 +58,37 @@ class MultiHeadAttention(nn.Module):
             self._qkv_shadow = self.store.group_shadow_views(self.wq.vname + ".kernel")[0]
         return self._qkv_shadow
 
-    def forward(self, v, k, q, mask):
-        """Returns (output, None): the [B,h,Tq,Tk] attention weights are never materialised."""
+    def attention_weights(self, k, q, mask):
+        """softmax(q k^T / sqrt(depth) + mask) of this module's projections as an fp32 tensor
+        [B, h, Tq, Tk]: the second value MultiHeadAttention.call returns in the reference
+        (attention.py:161,171).  Computed on request, without gradient; the fused kernels of the
+        forward pass never write it."""
+        import math
+        from .. import ops
+        from .fused import lin_fwd
+        m = AttnMask.coerce(mask)
+        self.store.refresh_shadows()
+        B, Tq, d = q.shape
+        Tk = k.shape[1]
+        with torch.no_grad():
+            qp, _ = lin_fwd(q.contiguous().reshape(B * Tq, d), B * Tq, self.wq)
+            kp, _ = lin_fwd(k.contiguous().reshape(B * Tk, d), B * Tk, self.wk)
+            band = 1 if m.causal else self.band
+            return ops.mha_weights(qp, kp, d, d, m.key_mask, band, B, self.num_heads, Tq, Tk, self.depth,
+                                   1.0 / math.sqrt(self.depth))
+
+    def forward(self, v, k, q, mask, return_attention_weights=False):
+        """Returns (output, attention weights): the [B,h,Tq,Tk] weights are not materialised by the
+        fused kernels and are None unless ``return_attention_weights`` asks for them (they then come
+        from a separate pass, see ``attention_weights``)."""
         from .fused import MultiHeadAttentionFn
-        if k is not v:
-            raise NotImplementedError("MultiHeadAttention: k and v must be the same tensor")
+        if k is not v and not (k.data_ptr() == v.data_ptr() and k.shape == v.shape and k.stride() == v.stride()):
+            raise NotImplementedError("MultiHeadAttention: k and v must be the same tensor (the transformer "
+                                      "layers never pass different ones: transformer.py:304,383,385)")
         m = AttnMask.coerce(mask)
         self.store.refresh_shadows()
         # a look-ahead mask (band 1) and the layer's own band: the narrower one decides
         band = 1 if m.causal else self.band
         out = MultiHeadAttentionFn.apply(q.contiguous(), k.contiguous(), self, m.key_mask, band,
                                          *self.parameters())
-        return out, None
+        return out, (self.attention_weights(k, q, m) if return_attention_weights else None)

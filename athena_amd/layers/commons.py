@@ -8,6 +8,14 @@ from ..runtime import constant, glorot_uniform
 
 ACTIVATIONS = {"relu6": ops.ACT_RELU6, "gelu": ops.ACT_GELU, "linear": ops.ACT_NONE}
 
+# The activation of the feed-forward block by name (reference ACTIVATIONS, athena/layers/commons.py:494-506):
+# name -> (epilogue of the forward product, epilogue of the backward product, which multiplies by the
+# derivative at the saved pre-activation).  "glu" halves the width of its input and is not a
+# feed-forward activation the transformer layers can take.
+_UNARY = ["relu", "elu", "selu", "leaky_relu", "sigmoid", "softplus", "softsign", "tanh", "relu6"]
+FFN_ACTIVATIONS = {"gelu": (ops.ACT_GELU, ops.ACT_MUL_DGELU)}
+FFN_ACTIVATIONS.update({n: (ops.ACT_UNARY + k, ops.ACT_MUL_DUNARY + k) for k, n in enumerate(_UNARY)})
+
 
 class _Bound(nn.Module):
     """A module whose variables live in a ParamStore; ``bind()`` creates the Parameter views."""

@@ -234,7 +234,8 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
 def ffn_fwd(x, M, layer, p, rng):
     """Dense(dff, gelu) -> Dropout -> Dense(d); the trailing Dropout is applied by the caller's
     add+LayerNorm kernel (transformer.py:262-282)."""
-    h, h_pre = lin_fwd(x, M, layer.ffn0, act=ACT_GELU, want_pre=True, drop_p=p, rng=rng, site=layer.site_ffn_h)
+    h, h_pre = lin_fwd(x, M, layer.ffn0, act=getattr(layer, "ffn_act", ACT_GELU), want_pre=True, drop_p=p, rng=rng,
+                       site=layer.site_ffn_h)
     f, _ = lin_fwd(h, M, layer.ffn1)
     return f, (h_pre, h)
 
@@ -244,7 +245,8 @@ def ffn_bwd(df, x, M, layer, saved, p, rng, dx):
     h_pre, h = saved
     d, dff = layer.ffn0.in_features, layer.ffn0.out_features
     lin_bwd_w(h, df, M, layer.ffn1, dff, d, defer=df.data_ptr() != dx.data_ptr())
-    dh = lin_bwd_x(df, M, layer.ffn1, d, act=ACT_MUL_DGELU, aux=h_pre, drop_p=p, rng=rng, site=layer.site_ffn_h)
+    dh = lin_bwd_x(df, M, layer.ffn1, d, act=getattr(layer, "ffn_dact", ACT_MUL_DGELU), aux=h_pre, drop_p=p, rng=rng,
+                   site=layer.site_ffn_h)
     lin_bwd_w(x, dh, M, layer.ffn0, d, dff)
     lin_bwd_x(dh, M, layer.ffn0, dff, out=dx, accumulate=True)
 

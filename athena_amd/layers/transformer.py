@@ -4,7 +4,13 @@ from torch import nn
 
 from ..runtime import truncated_normal
 from .attention import AttnMask, MultiHeadAttention
-from .commons import Dense, LayerNormParams
+from .commons import FFN_ACTIVATIONS, Dense, LayerNormParams
+
+
+def _ffn_activation(name):
+    if name not in FFN_ACTIVATIONS:
+        raise NotImplementedError("ffn activation %r (built: %s)" % (name, ", ".join(sorted(FFN_ACTIVATIONS))))
+    return FFN_ACTIVATIONS[name]
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -14,15 +20,17 @@ class TransformerEncoderLayer(nn.Module):
     def __init__(self, store, name, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="gelu",
                  unidirectional=False, look_ahead=0, conv_module_kernel_size=0):
         super().__init__()
-        if activation != "gelu":
-            raise NotImplementedError("only the default 'gelu' FFN activation is built")
+        self.ffn_act, self.ffn_dact = _ffn_activation(activation)
         if conv_module_kernel_size > 0:
             raise NotImplementedError("conv_module_kernel_size > 0 (conformer conv module) is not built")
         self.store, self.rate = store, dropout
         self.self_attn = MultiHeadAttention(store, name + ".self_attn", d_model, nhead, unidirectional, look_ahead)
         init = truncated_normal(0.02)
-        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=True)
-        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=True)
+        # the one-launch layer tail is built for the default gelu; any other activation runs the block
+        # as separate products (no fragment-tiled weight copies, which is what selects the tail)
+        tail = activation == "gelu"
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=tail)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=tail)
         self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
         self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
         self.site_res1, self.site_ffn_h, self.site_res2 = store.new_site(), store.new_site(), store.new_site()
@@ -38,22 +46,35 @@ class TransformerDecoderLayer(nn.Module):
 
     def __init__(self, store, name, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="gelu"):
         super().__init__()
-        if activation != "gelu":
-            raise NotImplementedError("only the default 'gelu' FFN activation is built")
+        self.ffn_act, self.ffn_dact = _ffn_activation(activation)
         self.store, self.rate = store, dropout
         self.attn1 = MultiHeadAttention(store, name + ".attn1", d_model, nhead)
         self.attn2 = MultiHeadAttention(store, name + ".attn2", d_model, nhead)
         init = truncated_normal(0.02)
-        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=True)
-        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=True)
+        tail = activation == "gelu"
+        self.ffn0 = Dense(store, name + ".ffn.0", d_model, dim_feedforward, init, tiled=tail)
+        self.ffn1 = Dense(store, name + ".ffn.1", dim_feedforward, d_model, init, tiled=tail)
         self.norm1 = LayerNormParams(store, name + ".norm1", d_model)
         self.norm2 = LayerNormParams(store, name + ".norm2", d_model)
         self.norm3 = LayerNormParams(store, name + ".norm3", d_model)
         self.site_res1, self.site_res2 = store.new_site(), store.new_site()
         self.site_ffn_h, self.site_res3 = store.new_site(), store.new_site()
 
+    def cross_attention_weights(self, tgt, memory, tgt_mask=None, memory_mask=None):
+        """The weights of this layer's encoder-decoder attention for the input ``tgt`` (the second
+        value of TransformerDecoderLayer.call, transformer.py:383-388), without dropout: the
+        self-attention sub-layer is run again eagerly to get the queries."""
+        from .fused import LN_EPS
+        from .. import ops
+        with torch.no_grad():
+            a, _ = self.attn1(tgt, tgt, tgt, tgt_mask)
+            z, y, _, _ = ops.add_layernorm_fwd(tgt.contiguous(), a.contiguous(), self.norm1.gamma, self.norm1.beta,
+                                               LN_EPS, 0.0, self.store.rng_state, 0)
+            return self.attn2.attention_weights(memory, y, memory_mask)
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, training=None):
-        """Returns (output, None); the reference's second value (cross-attention weights) is not kept."""
+        """Returns (output, None); the cross-attention weights are available through
+        ``cross_attention_weights``."""
         from .fused import DecoderLayerFn
         tm, mm = AttnMask.coerce(tgt_mask), AttnMask.coerce(memory_mask)
         if not tm.causal and tgt_mask is not None:
@@ -131,10 +152,15 @@ class TransformerDecoder(nn.Module):
             layer.__dict__.pop("_pending_dx", None)
             layer.__dict__.pop("_pre_kv", None)
         self._project_memory(memory)
+        weights = []
         for layer in self.layers:
+            if return_attention_weights:
+                # the cross-attention weights of each layer (transformer.py:225-231), from the layer's input
+                # to that attention: a separate pass, the fused layer kernels do not write them
+                weights.append(layer.cross_attention_weights(output, memory, tgt_mask, memory_mask))
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, training=training)
         if return_attention_weights:
-            raise NotImplementedError("attention weights are not materialised by the fused kernels")
+            return output, weights
         return output
 
 

@@ -9,7 +9,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_MUL_DGELU, ACT_MUL_DRELU6, ACT_NONE, ACT_RELU6, BF16, F32  # noqa: F401
+from ._lib import (ACT_GELU, ACT_MUL_DGELU, ACT_MUL_DRELU6, ACT_MUL_DUNARY, ACT_NONE, ACT_RELU6, ACT_UNARY, BF16,  # noqa: F401
+                   F32)
 
 
 def dt(t):
@@ -453,6 +454,16 @@ def mha_bwd(q, k, v, ldq, ldk, ldv, key_mask, causal, B, h, Tq, Tk, dk, scale, o
     _lib.check(lib.athena_mha_bwd(_ptr(q), _ptr(k), _ptr(v), ldq, ldk, ldv, _ptr(key_mask), int(causal), B, h,
                                   Tq, Tk, dk, dt(q), scale, _ptr(out), _ptr(dout), ldo, _ptr(lse), _ptr(delta),
                                   _ptr(dq), _ptr(dk_), _ptr(dv), lddq, lddk, lddv, _stream()), "athena_mha_bwd")
+
+
+def mha_weights(q, k, ldq, ldk, key_mask, causal, B, h, Tq, Tk, dk, scale):
+    """softmax(q k^T * scale + mask) as an fp32 tensor [B, h, Tq, Tk] (the inspection path)."""
+    if q.dtype != k.dtype or _extent(q) < (B * Tq - 1) * ldq + h * dk or _extent(k) < (B * Tk - 1) * ldk + h * dk:
+        raise RuntimeError("athena_amd.mha_weights: bad operands")
+    w = torch.empty((B, h, Tq, Tk), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().athena_mha_weights(_ptr(q), _ptr(k), ldq, ldk, _ptr(key_mask), int(causal), B, h, Tq, Tk, dk,
+                                              dt(q), scale, _ptr(w), _stream()), "athena_mha_weights")
+    return w
 
 
 # ------------------------------------------------------------------------------------------ conv / BN

@@ -111,9 +111,17 @@ def multi_head_attention(p, name, v_in, k_in, q_in, mask, num_heads, unidirectio
     return dense(out, p, name + ".dense"), w
 
 
-def ffn(p, name, x, rate, training):
-    """Dense(dff, gelu) -> Dropout -> Dense(d) -> Dropout (transformer.py:262-282)."""
-    h = gelu_tanh(dense(x, p, name + ".0"))
+# ACTIVATIONS of athena/layers/commons.py:494-506 (without glu, which halves its input's width)
+FFN_ACTIVATIONS = {
+    "gelu": lambda x: gelu_tanh(x), "relu": F.relu, "relu6": lambda x: relu6(x), "elu": F.elu, "selu": F.selu,
+    "leaky_relu": lambda x: F.leaky_relu(x, 0.2), "sigmoid": torch.sigmoid, "softplus": F.softplus,
+    "softsign": F.softsign, "tanh": torch.tanh,
+}
+
+
+def ffn(p, name, x, rate, training, activation="gelu"):
+    """Dense(dff, activation) -> Dropout -> Dense(d) -> Dropout (transformer.py:262-282)."""
+    h = FFN_ACTIVATIONS[activation](dense(x, p, name + ".0"))
     h = F.dropout(h, rate, training)
     h = dense(h, p, name + ".1")
     return F.dropout(h, rate, training)
@@ -125,7 +133,7 @@ def encoder_layer(p, name, src, src_mask, cfg, training):
                                 cfg.get("unidirectional", False), cfg.get("look_ahead", 0))
     out = layer_norm(src + F.dropout(a, cfg["rate"], training),
                      p[name + ".norm1.gamma"], p[name + ".norm1.beta"])
-    out = layer_norm(out + ffn(p, name + ".ffn", out, cfg["rate"], training),
+    out = layer_norm(out + ffn(p, name + ".ffn", out, cfg["rate"], training, cfg.get("ffn_activation", "gelu")),
                      p[name + ".norm2.gamma"], p[name + ".norm2.beta"])
     return out
 
@@ -138,7 +146,7 @@ def decoder_layer(p, name, tgt, memory, tgt_mask, memory_mask, cfg, training):
     a2, w2 = multi_head_attention(p, name + ".attn2", memory, memory, out, memory_mask, cfg["num_heads"])
     out = layer_norm(out + F.dropout(a2, cfg["rate"], training),
                      p[name + ".norm2.gamma"], p[name + ".norm2.beta"])
-    out = layer_norm(out + ffn(p, name + ".ffn", out, cfg["rate"], training),
+    out = layer_norm(out + ffn(p, name + ".ffn", out, cfg["rate"], training, cfg.get("ffn_activation", "gelu")),
                      p[name + ".norm3.gamma"], p[name + ".norm3.beta"])
     return out, w2
 

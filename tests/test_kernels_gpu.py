@@ -1418,3 +1418,123 @@ def test_accuracy_metrics_score_on_the_device():
     short = torch.randn(B, U + 1, V).to(dev())
     m(short, ds, tl.to(dev()))                                      # skipped (metrics.py:124-125)
     assert m.result() != m.result()
+
+
+# ------------------------------------------------------------------------------------------ ffn activations, attention weights
+def _oracle_params(store, cd):
+    pr = {}
+    for k, v in store.state_dict().items():
+        v = v.double()
+        if v.dim() == 2 and cd == torch.bfloat16:
+            v = v.to(torch.bfloat16).double()
+        pr[k] = v.requires_grad_(True)
+    return pr
+
+
+@pytest.mark.parametrize("activation", ["relu", "relu6", "elu", "selu", "leaky_relu", "sigmoid", "softplus", "softsign",
+                                        "tanh", "gelu"])
+def test_encoder_layer_ffn_activations(activation):
+    """TransformerEncoderLayer with every feed-forward activation of the reference's table
+    (athena/layers/commons.py:494-506, used at transformer.py:262-270) against the oracle layer in fp64:
+    output 2e-5, every gradient 1e-4 (fp32 mode)."""
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    d, h, dff, B, T = 64, 4, 80, 3, 11
+    store = ParamStore(torch.float32, device=dev())
+    layer = TransformerEncoderLayer(store, "enc", d, h, dff, 0.0, activation=activation)
+    store.finalize(seed=3)
+    bind_all(layer)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for name, p_ in layer.named_parameters():
+            p_.add_((0.3 if p_.dim() == 1 else 0.15) * torch.randn(p_.shape, generator=g).to(p_.device))
+    store.refresh_shadows(force=True)
+    x = torch.randn(B, T, d, generator=g) * 1.5
+    dy = torch.randn(B, T, d, generator=g)
+    xg = x.to(dev()).requires_grad_(True)
+    store.grads.zero_()
+    y = layer(xg, None, training=True)
+    y.backward(dy.to(dev()))
+    torch.cuda.synchronize()
+    pr = _oracle_params(store, torch.float32)
+    xr = x.double().requires_grad_(True)
+    yr = om.encoder_layer(pr, "enc", xr, None, {"num_heads": h, "rate": 0.0, "ffn_activation": activation}, training=True)
+    yr.backward(dy.double())
+    assert_close(y, yr.detach(), 2e-5, "layer output (%s)" % activation)
+    assert_close(xg.grad, xr.grad, 1e-4, "input gradient (%s)" % activation)
+    for n_, p_ in layer.named_parameters():
+        key = "enc." + n_.replace("ffn0", "ffn.0").replace("ffn1", "ffn.1")
+        if key.endswith("wk.bias"):
+            continue
+        assert_close(p_.grad, pr[key].grad, 1e-4, key)
+
+
+def test_unknown_ffn_activation_is_refused():
+    from athena_amd.layers.transformer import TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    with pytest.raises(NotImplementedError):
+        TransformerEncoderLayer(ParamStore(torch.float32, device=dev()), "enc", 32, 4, 64, 0.0, activation="glu")
+
+
+@pytest.mark.parametrize("cd", DTYPES)
+def test_attention_weights_on_request(cd):
+    """MultiHeadAttention(..., return_attention_weights=True): the [B, h, Tq, Tk] weights the reference
+    returns beside the output (athena/layers/attention.py:161,171) against the oracle's, with a key
+    padding mask, with the causal mask, and for a unidirectional layer with look-ahead; and the
+    decoder stack's list of cross-attention weights (transformer.py:225-231)."""
+    from athena_amd.layers.attention import AttnMask, MultiHeadAttention
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerDecoder, TransformerDecoderLayer
+    from athena_amd.runtime import ParamStore
+    d, h, B, Tq, Tk = 64, 4, 2, 9, 13
+    store = ParamStore(cd, device=dev())
+    mha = MultiHeadAttention(store, "a", d, h)
+    uni = MultiHeadAttention(store, "u", d, h, unidirectional=True, look_ahead=2)
+    dec = TransformerDecoder([TransformerDecoderLayer(store, "dec.%d" % i, d, h, 96, 0.0) for i in range(2)])
+    store.finalize(seed=6)
+    for m in (mha, uni, dec):
+        bind_all(m)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in (mha, uni, dec):
+            for p_ in m.parameters():
+                p_.add_((0.3 if p_.dim() == 1 else 0.2) * torch.randn(p_.shape, generator=g).to(p_.device))
+    store.refresh_shadows(force=True)
+    pr = _oracle_params(store, cd)
+    tol = 1e-5 if cd == torch.float32 else 2e-2
+    q = rounded(torch.randn(B, Tq, d, generator=g, dtype=torch.float64), cd)
+    kv = rounded(torch.randn(B, Tk, d, generator=g, dtype=torch.float64), cd)
+    pad = torch.zeros(B, Tk, dtype=torch.uint8)
+    pad[1, 9:] = 1
+    fmask = pad.double()[:, None, None, :]
+    with torch.no_grad():
+        kvd, qd = to_cd(kv, cd), to_cd(q, cd)
+        out, w = mha(kvd, kvd, qd, AttnMask(pad.to(dev()), False), return_attention_weights=True)
+        out_r, w_r = om.multi_head_attention(pr, "a", kv, kv, q, fmask, h)
+        assert tuple(w.shape) == (B, h, Tq, Tk)
+        assert_close(w, w_r, tol, "weights, padding mask")
+        assert_close(out, out_r, TOL[cd], "output unchanged by the request")
+        assert mha(kvd, kvd, qd, None)[1] is None
+        # causal self-attention
+        causal = torch.triu(torch.ones(Tq, Tq, dtype=torch.float64), diagonal=1)[None, None]
+        _, w = mha(qd, qd, qd, AttnMask(None, True), return_attention_weights=True)
+        _, w_r = om.multi_head_attention(pr, "a", q, q, q, causal, h)
+        assert_close(w, w_r, tol, "weights, causal mask")
+        # unidirectional layer, look-ahead 2
+        _, w = uni(qd, qd, qd, None, return_attention_weights=True)
+        _, w_r = om.multi_head_attention(pr, "u", q, q, q, None, h, unidirectional=True, look_ahead=2)
+        assert_close(w, w_r, tol, "weights, band")
+        # decoder stack
+        tgt = qd
+        y, ws = dec(tgt, kvd, tgt_mask=AttnMask(None, True), memory_mask=AttnMask(pad.to(dev()), False),
+                    return_attention_weights=True, training=False)
+        y_plain = dec(tgt, kvd, tgt_mask=AttnMask(None, True), memory_mask=AttnMask(pad.to(dev()), False),
+                      training=False)
+        assert len(ws) == 2 and all(tuple(w_.shape) == (B, h, Tq, Tk) for w_ in ws)
+        assert torch.equal(y, y_plain)
+        t_r = q
+        for i in range(2):
+            t_next, w_r = om.decoder_layer(pr, "dec.%d" % i, t_r, kv, causal, fmask, {"num_heads": h, "rate": 0.0}, False)
+            assert_close(ws[i], w_r, tol if cd == torch.float32 else 4e-2, "cross-attention weights of layer %d" % i)
+            t_r = t_next
