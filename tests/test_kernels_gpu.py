@@ -1336,7 +1336,8 @@ def _ref_counts(ids, lens, labels, mode, special):
 
 
 @pytest.mark.parametrize("B,L,U,V", [(5, 40, 7, 6), (32, 250, 32, 4233), (8, 750, 150, 50), (3, 90, 64, 9),
-                                     (4, 300, 200, 5), (2, 17, 1, 4)])
+                                     (4, 300, 200, 5), (2, 17, 1, 4), (2, 255, 300, 7), (2, 256, 30, 7), (1, 1500, 1200, 11),
+                                     (1, 3000, 40, 5)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_seq_errors_matches_oracle_loops(ops, B, L, U, V, mode):
     """athena_seq_errors against the oracle's greedy decode / validate_seqs + edit distance: ragged
@@ -1383,8 +1384,8 @@ def test_seq_errors_eos_zero_and_limits(ops):
     per = torch.zeros(1, 2, dtype=torch.int32, device=dev())
     ops.seq_errors(ids, None, labels, 1, 0, per_utt=per)          # eos == 0: only the zeros go
     assert per.cpu().tolist() == [[1, 3]]
-    with pytest.raises(RuntimeError):
-        ops.seq_errors(ids, None, torch.zeros(1, 1025, dtype=torch.int32, device=dev()), 1, 0, per_utt=per)
+    with pytest.raises(RuntimeError):                               # more ids per utterance than a wave's registers hold
+        ops.seq_errors(torch.zeros(1, 4096, dtype=torch.int32, device=dev()), None, labels, 1, 0, per_utt=per)
 
 
 def test_accuracy_metrics_score_on_the_device():
