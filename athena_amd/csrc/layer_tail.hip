@@ -225,7 +225,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
             if (thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, thresh, dscale, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[i][j][r] = lt_round(res[i][j][r] + (v[i][j][r] + bb[r]) * dm[r]);
+                v[i][j][r] = res[i][j][r] + (v[i][j][r] + bb[r]) * dm[r];
                 s[i] += v[i][j][r];
             }
             lt_store4(zimg + lt_img_off(16 * i + fr, n), v[i][j]);
@@ -283,7 +283,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
             const float4 t4 = *(const float4*)(beta + n);
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[i][j][r] = lt_round((v[i][j][r] - mu[i]) * rs * gg[r] + tt[r]);
+            for (int r = 0; r < 4; ++r) v[i][j][r] = (v[i][j][r] - mu[i]) * rs * gg[r] + tt[r];
             lt_store4(yimg + lt_img_off(16 * i + fr, n), v[i][j]);
         }
     }

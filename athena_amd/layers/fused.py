@@ -113,6 +113,12 @@ class _WgradQueue:
     items = []
     queued = False
     enabled = os.environ.get("ATHENA_WGRAD_TABLE", "1") != "0"
+    # A stream to run the table on instead of the launch stream (None: the launch stream).  The
+    # data-parallel step cuts its backward pass into pieces and exchanges each piece's gradients on a
+    # side stream while the next piece runs; a piece's table has too few tiles to fill the chip, so it
+    # goes to that side stream as well -- in front of the exchange that needs its results, beside the
+    # next piece's kernels -- instead of standing in the way on the launch stream.
+    side = None
 
     @classmethod
     def push(cls, item):
@@ -128,7 +134,16 @@ class _WgradQueue:
     @classmethod
     def flush(cls):
         items, cls.items, cls.queued = cls.items, [], False
-        ops.gemm_wgrad_table(items)
+        if cls.side is None or not items:
+            ops.gemm_wgrad_table(items)
+            return
+        main = torch.cuda.current_stream()
+        cls.side.wait_stream(main)                      # the operands are complete on the launch stream
+        for it in items:
+            it[0].record_stream(cls.side)               # x and dy must outlive the side stream's use of them
+            it[1].record_stream(cls.side)
+        with torch.cuda.stream(cls.side):
+            ops.gemm_wgrad_table(items)
 
 
 def lin_bwd_w(x, dy, M, dense, ldx, lddy, defer=True):

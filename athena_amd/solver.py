@@ -387,9 +387,15 @@ class _OneGraphPipelinedStep:
             for lo in range(a, b, step):
                 works.append(solver._exchange_async(grads[lo:min(lo + step, b)]))
 
+        from .layers.fused import _WgradQueue
+        side_tables = solver._rccl is not None and os.environ.get("ATHENA_DP_SIDE_TABLES", "1") != "0"
+        if side_tables and solver._side is None:
+            solver._side = torch.cuda.Stream()
         store.collect_cuts = True
         store.shadows_dirty = True          # the refresh is always part of the recorded forward pass
         try:
+            # each piece's weight-gradient table runs on the side stream, in front of the piece's exchange
+            _WgradQueue.side = solver._side if side_tables else None
             with _capture(self.graph, solver._graph_pool()), ops.bf16_grad_handover():
                 outputs = solver.model(self.inputs, training=True)
                 self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
@@ -411,6 +417,7 @@ class _OneGraphPipelinedStep:
                         w.wait()
                 solver._update(1.0 / max(solver.world_size, 1))
         finally:
+            _WgradQueue.side = None
             store.collect_cuts = False
             store.cuts = []
         self._keep = (cuts, g_mem, g_y, up, g_up)          # the graph's buffers must outlive it

@@ -191,10 +191,14 @@ def test_full_size_step_bf16(full_oracle):
           (o["name"], float(ea.max()), float(ec.max()), float(ea.pow(2).mean().sqrt()),
            float(ec.pow(2).mean().sqrt()), scale))
     # stated tolerance: root-mean-square error 1e-2 absolute; the largest single error among the
-    # tens of millions of logits (a six-sigma event of that noise) within 4e-2 absolute or 1.5 % of the
-    # logit scale (bf16 keeps 8 significant bits per GEMM operand through the layer stack)
+    # tens of millions of logits (a six-sigma event of that noise) within the bound below (bf16 keeps 8
+    # significant bits per GEMM operand through the layer stack)
     assert float(ea.pow(2).mean().sqrt()) <= 1e-2 and float(ec.pow(2).mean().sqrt()) <= 1e-2
-    assert float(ea.max()) <= max(4e-2, 1.5e-2 * scale) and float(ec.max()) <= max(4e-2, 1.5e-2 * scale)
+    # (AISHELL size, d_model 256: the one-launch layer tails keep the residual stream and the LayerNorms
+    # in fp32 -- measured 1.1e-2 / 1.4e-2; the d_model 512 recipes run their layers as separate launches
+    # that round the stream to bf16 between them -- measured 2.4e-2 / 3.0e-2 at a logit scale of 2.3)
+    bound = 2e-2 if o["name"] == "aishell" else max(3.5e-2, 1.5e-2 * scale)
+    assert float(ea.max()) <= bound and float(ec.max()) <= bound
     loss, _ = model.get_loss((att, ctc), ds, training=True)
     assert abs(float(loss) - o["loss"]) <= 2e-3 * abs(o["loss"]), (float(loss), o["loss"])
     loss.backward()
