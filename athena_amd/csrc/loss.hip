@@ -9,7 +9,9 @@
 //   ctc_lattice : one workgroup per sample: alpha and beta recursions in two wavefronts (states in
 //                 registers, probabilities in double precision with power-of-two rescaling), two
 //                 more wavefronts copying the state vectors from an LDS ring to memory; a sample
-//                 without a path is redone on logarithms the way TensorFlow's dense branch does it
+//                 without a path, with a state beyond the double range, or on which the finite
+//                 log-zeros of TensorFlow's dense branch would show in the result is redone on
+//                 logarithms the way that branch does it
 //   ctc_post    : one wave per logits row: the state posterior alpha*beta, normalised, as a short
 //                 list (blank, label 1, label 2, ...), the loss of each sample, and on the one-pass
 //                 path the gradient columns that have an occupancy
@@ -535,7 +537,8 @@ __device__ __forceinline__ double lse_pair(double a, double b) {
 
 // The slow path of the lattice launch, for a sample the recursion found no path for (path sum zero:
 // the labels do not fit the frames, or an emission fell outside what the probability-domain
-// recursion holds), on the four waves of the sample's workgroup: tf.nn.ctc_loss's dense
+// recursion holds) or whose fitting alignments are so much less likely than those through a wrong
+// start or end state that TensorFlow's finite log-zeros show, on the four waves of the sample's workgroup: tf.nn.ctc_loss's dense
 // recursion restated literally (reference call site athena/loss.py:38-45) -- every one of the U label
 // states and U+1 blank states of the padded label row plus the silent start state, the leaky initial
 // and final vectors, the loss read from the backward recursion -- in double precision on logarithms,
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
     static_assert(sizeof(CtcSlowLds) <= 2 * DS * Sp * 8, "the slow path borrows the ring");
     __shared__ __attribute__((aligned(16))) double ring_s[2][DS][Sp];
     __shared__ int prod[2], cons[2];
-    __shared__ int no_path;
+    __shared__ int no_path, beta_broke;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = (threadIdx.x >> 6) & 1;
@@ -1051,8 +1054,8 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
     // Scaling.  Every fourth step two compares tell whether the largest state of the wave has left
     // [2^-256, 2^256]; only then is its exponent found (a reduction over the wave) and taken out of
     // every state.  An emission within 2^(+-130) per step cannot carry a state from that band to the
-    // end of the double range in four steps; one beyond that leaves a zero or non-finite path sum,
-    // and the sample goes to the slow path.
+    // end of the double range in four steps; one beyond that leaves a zero path sum or a state that
+    // is not finite, and the sample goes to the slow path.
     auto rescale = [&]() {
         int mh = __double2hiint(a[0]);
 #pragma unroll
@@ -1065,6 +1068,28 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
             for (int r = 0; r < R; ++r) a[r] = ldexp(a[r], -k);
             cum += k;
         }
+    };
+    // An infinity or a NaN in a state stays one to the end of the recursion (every state is a term of
+    // its own successor), so one look at the last vector tells whether any state ever left the
+    // double range -- also one that no fitting alignment passes through and the path sum does not
+    // see, whose product with a zero of the other lattice would be a NaN in the posterior.
+    auto states_finite = [&]() {
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) bad |= !(a[r] < (double)INFINITY);
+        return __ballot(bad) == 0;
+    };
+    // TensorFlow's recursion starts and ends on finite log-zeros (CTC_TF_LOG0 below) where this one has
+    // true zeros.  Its result shows that only when alignments that start or end in a wrong state are
+    // about e^707 = 2^1020 times likelier than the fitting ones: the last alpha vector (for the end)
+    // and the last beta vector times the first frame's emissions (for the start) tell.  From the
+    // largest high word of all states and of the legal ones: true when the two are more than 2^960
+    // apart -- from there on the leak may reach the fp32 result, and the sample is the slow path's,
+    // which restates TensorFlow's recursion literally.
+    auto leak_shows = [&](int hi_all, int hi_legal) {
+        const int e_all = (wave_imax_dpp(hi_all) >> 20) & 0x7ff;
+        const int e_legal = (wave_imax_dpp(hi_legal) >> 20) & 0x7ff;
+        return e_all - e_legal > 960;
     };
     // vector i = 1 + k * PF + j of trip k goes into slot (k * PF + j) % DS: ``base`` is the trip's
     // part of that, j the compile-time part
@@ -1160,12 +1185,21 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) fin += __shfl_xor(fin, o, 64);
+        int hi_all = 0, hi_end = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = lane * R + r;
+            hi_all = max(hi_all, __double2hiint(a[r]));
+            if (s == Sb - 1 || (s == Sb - 2 && Sb >= 2)) hi_end = max(hi_end, __double2hiint(a[r]));
+        }
+        const bool whole = states_finite() && !leak_shows(hi_all, hi_end);
         if (lane == 0) {
-            const bool ok = fin > 0.0 && fin < (double)INFINITY;
+            const bool ok = fin > 0.0 && fin < (double)INFINITY && whole;
             ll[b] = ok ? (double)cum + log2(fin) : -(double)INFINITY;
             no_path = ok ? 0 : 1;
         }
     } else {
+        bool start_leak;
         // ---------------- beta: vector i is time len-1-i.  beta[len-1][s] = 1 for final states;
         // beta[t][s] = sum over successors s' in {s, s+1, s+2(skip)} of beta[t+1][s'] * p[t+1][s'],
         // so step i reads the emissions of time len-i
@@ -1192,6 +1226,11 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
             if (len == 1) lds_poke(&prod[dir], 1);
             ep = eb - 1 + (long)(len - 1) * Lp;
             trips(step, -Lp);
+            // the start states 0 and 1: slot 1 of lane 0 and slot 0 of lane 1
+            double p0[HR];
+            load_states<HR>(eb - 1, p0);
+            const int h0 = __double2hiint(a[0] * p0[0]), h1 = __double2hiint(a[1]);
+            start_leak = leak_shows(max(h0, h1), max(lane == 1 ? h0 : 0, lane == 0 ? h1 : 0));
         } else {
         auto step = [&](const double (&p)[HR], int ph) {
             double w[R];
@@ -1221,12 +1260,32 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const double* __restri
         if (len == 1) lds_poke(&prod[dir], 1);
         ep = eb + (long)(len - 1) * Lp;
         trips(step, -Lp);
+        double p0[HR];
+        load_states<HR>(eb, p0);
+        int hi_all = 0, hi_start = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int h = __double2hiint((r % 2) == 0 ? a[r] : a[r] * p0[r >> 1]);
+            hi_all = max(hi_all, h);
+            if (lane * R + r < 2) hi_start = max(hi_start, h);
         }
+        start_leak = leak_shows(hi_all, hi_start);
+        }
+        const bool whole = states_finite() && !start_leak;
+        if (lane == 0) beta_broke = whole ? 0 : 1;
     }
     __builtin_amdgcn_s_setprio(0);
     }
     // all four waves meet here; the ring is no longer in use
     __syncthreads();
+    if (beta_broke && !no_path) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ll[b] = -(double)INFINITY;          // (thread 0 wrote the path sum there itself)
+            no_path = 1;
+        }
+        __syncthreads();
+    }
     if (no_path)
         ctc_slow_path<T, TG>(*reinterpret_cast<CtcSlowLds*>(&ring_s[0][0][0]), b, logits, ldl, labels, label_len,
                              logit_len, T_, V, U, blank, Sp, Up, lse, alpha, occ, first_g, flags, loss, gscale, grad);

@@ -817,6 +817,46 @@ def test_ctc_extreme_logits_fall_back_to_the_log_domain(ops):
     assert_close(grad, grad_ref, 1e-4, "ctc grad with extreme logits")
 
 
+@pytest.mark.parametrize("where", ["end", "start", "both"])
+def test_ctc_follows_tensorflow_where_its_finite_log_zero_shows(ops, where):
+    """TensorFlow's dense branch starts and ends its recursion on a finite log-zero, log(1e-307) =
+    -706.9, for the states an alignment may not start or end in, and reads the loss from the backward
+    scan.  When the last frame puts e^-708 on both legal end states (the last label and the blank) and
+    ordinary mass on the others, alignments that end in a wrong state are likelier than the fitting
+    ones and leak into its loss and gradient; the same at the first frame changes its gradient only.
+    The textbook recursion (true zeros) gives another value there.  The kernels notice from their last
+    alpha / beta vectors that the leak would show and hand the utterance to the path that restates
+    TensorFlow's recursion: loss and gradient follow oracle.ctc.ctc_loss_tf_dense, and the test
+    asserts that the two statements really differ on this input."""
+    rng = np.random.default_rng(11)
+    B, T, V, U = 2, 12, 6, 3
+    logits = np.float32(rng.normal(size=(B, T, V)))
+    labels = np.array([[1, 2, 3], [2, 4, 1]], np.int32)
+    if where in ("end", "both"):
+        logits[0, T - 1, V - 1] = -708.0       # the blank and the last label of utterance 0, last frame
+        logits[0, T - 1, 3] = -708.0
+    if where in ("start", "both"):
+        logits[0, 0, V - 1] = -708.0           # the blank and its first label, first frame
+        logits[0, 0, 1] = -708.0
+    llen = np.array([3, 3], np.int32)
+    tlen = np.array([T, T], np.int32)
+    l64 = logits.astype(np.float64)
+    loss_tf, grad_tf = octc.ctc_loss_tf_dense(l64, labels, llen, tlen, blank_index=-1)
+    loss_tb, grad_tb = octc.ctc_loss_textbook(l64, labels, llen, tlen, blank_index=-1)
+    assert loss_tb[0] > 707.0
+    if where != "start":
+        assert loss_tb[0] - loss_tf[0] > 0.2                               # the two statements differ
+    assert np.abs(grad_tf[0] - grad_tb[0]).max() > 0.1
+    assert abs(loss_tf[1] - loss_tb[1]) < 1e-9 * loss_tb[1]                # an ordinary utterance: they agree
+    per, grad, _ = _run_ctc_fused(ops, logits, labels, llen, tlen)
+    assert torch.isfinite(grad).all()
+    assert_close(per, loss_tf, 1e-5, "ctc loss where the finite log-zero shows")
+    assert_close(grad, grad_tf, 1e-4, "ctc gradient where the finite log-zero shows")
+    per2, grad2 = _run_ctc(ops, logits, labels, llen, tlen)
+    assert_close(per2, loss_tf, 1e-5, "ctc loss where the finite log-zero shows (two calls)")
+    assert_close(grad2, grad_tf, 1e-4, "ctc gradient where the finite log-zero shows (two calls)")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_rescale_unless(ops, dtype):
     x = torch.randn(5, 1000, device=dev()).to(dtype)
