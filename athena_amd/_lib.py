@@ -41,6 +41,14 @@ class WgradItem(Structure):
     ]
 
 
+class WgradFold(Structure):
+    """Mirror of ``athena_wgrad_fold``."""
+    _fields_ = [
+        ("dst", c_void_p), ("src", c_void_p), ("n", c_int64), ("part_stride", c_int64),
+        ("parts", c_int32), ("first_block", c_int32),
+    ]
+
+
 class LayerTailFwd(Structure):
     """Mirror of ``athena_layer_tail_fwd_desc``."""
     _fields_ = [
@@ -94,6 +102,10 @@ _SIGNATURES = {
     "athena_gemm_grouped": (c_int, [POINTER(GemmDesc), c_int, _S]),
     "athena_gemm_wgrad_plan": (c_int, [POINTER(WgradItem), c_int, POINTER(c_int)]),
     "athena_gemm_wgrad_table": (c_int, [_P, c_int, c_int, _S]),
+    "athena_gemm_wgrad_split": (c_int, [POINTER(WgradItem), c_int, c_int, _P, c_int64, POINTER(c_int64),
+                                        POINTER(WgradItem), c_int, POINTER(c_int), POINTER(WgradFold), c_int,
+                                        POINTER(c_int), POINTER(c_int)]),
+    "athena_gemm_wgrad_fold": (c_int, [_P, c_int, c_int, _S]),
     "athena_gemm_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "athena_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,

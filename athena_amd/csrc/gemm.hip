@@ -27,7 +27,7 @@ static int big_tiles_mode() {
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
-extern "C" int athena_abi_version(void) { return 11; }
+extern "C" int athena_abi_version(void) { return 12; }
 
 // ---------------------------------------------------------------- per-kernel timing sessions
 // Between athena_timing_begin and athena_timing_end every launch of the library carries two events
@@ -640,5 +640,154 @@ extern "C" int athena_gemm_wgrad_table(const athena_wgrad_item* table_dev, int c
     ATHENA_LAUNCH(gemm_big_table_kernel, dim3((unsigned)total_tiles), dim3(GB_THREADS), 0, (hipStream_t)stream,
                        (const GbItem*)table_dev, count);
     ATHENA_CHECK_LAUNCH("athena_gemm_wgrad_table");
+    return ATHENA_OK;
+}
+
+// ------------------------------------------------------------------ contraction split of a small table
+#define WG_FOLD_CHUNK 1024          // floats of one fold a workgroup sums
+
+extern "C" int athena_gemm_wgrad_split(const athena_wgrad_item* items, int count, int chip_tiles, float* workspace,
+                                       int64_t workspace_floats, int64_t* need_floats, athena_wgrad_item* out_items,
+                                       int out_capacity, int* out_count, athena_wgrad_fold* folds, int fold_capacity,
+                                       int* fold_count, int* fold_blocks) {
+    ATHENA_REQUIRE(items && count > 0 && need_floats && out_count && fold_count, ATHENA_E_SHAPE,
+                   "athena_gemm_wgrad_split: empty table or missing result pointers");
+    if (chip_tiles <= 0) chip_tiles = 256;
+    // The table's work in units of its longest contraction: that many workgroups are busy for the
+    // whole launch, the rest of the chip for less or not at all.
+    long kmax = 1, cost = 0;
+    for (int i = 0; i < count; ++i) {
+        const athena_wgrad_item& it = items[i];
+        ATHENA_REQUIRE(it.M > 0 && it.N > 0 && it.K > 0, ATHENA_E_SHAPE, "athena_gemm_wgrad_split: item %d: empty shape", i);
+        const long t = (long)((it.M + GB_BM - 1) / GB_BM) * ((it.N + GB_BN - 1) / GB_BN);
+        kmax = std::max(kmax, (long)it.K);
+        cost += t * it.K;
+    }
+    const long busy = (cost + kmax - 1) / kmax;
+    // parts of the longest contraction: as many as bring the table to about one workgroup per CU, of
+    // at least 1024 rows each (a part pays a prologue, an epilogue and a partial result of its own)
+    long s = std::min(std::min((long)chip_tiles / std::max(busy, 1L), 8L), kmax / 1024);
+    if (s < 2) s = 1;
+    const long part_rows = (kmax + s - 1) / s;
+    std::vector<int> parts(count, 1);
+    long need = 0, n_out = 0, n_fold = 0;
+    for (int i = 0; i < count; ++i) {
+        const athena_wgrad_item& it = items[i];
+        int pi = s > 1 ? (int)((it.K + part_rows / 2) / part_rows) : 1;      // rounded: no sliver of a part
+        if (pi < 2 || it.ldc != it.N) pi = 1;
+        parts[i] = pi;
+        n_out += pi;
+        if (pi > 1) {
+            need += (long)pi * (((long)it.M * it.N + 3) / 4 * 4 + (it.bsum ? ((long)it.N + 3) / 4 * 4 : 0));
+            n_fold += it.bsum ? 2 : 1;
+        }
+    }
+    *need_floats = need;
+    *out_count = (int)n_out;
+    *fold_count = (int)n_fold;
+    if (out_items == nullptr) return ATHENA_OK;       // the sizing call
+    ATHENA_REQUIRE(out_items && out_capacity >= n_out && (n_fold == 0 || (folds && fold_capacity >= n_fold && fold_blocks)),
+                   ATHENA_E_SHAPE, "athena_gemm_wgrad_split: room for %ld items and %ld folds needed", n_out, n_fold);
+    ATHENA_REQUIRE(need == 0 || workspace_floats >= need, ATHENA_E_SHAPE,
+                   "athena_gemm_wgrad_split: workspace of %ld floats needed", need);
+    ATHENA_REQUIRE(need == 0 || athena_aligned16(workspace), ATHENA_E_ALIGN,
+                   "athena_gemm_wgrad_split: workspace must be 16-byte aligned");
+    // Part p of every item, then part p + 1 of every item that has one: neighbours that share an
+    // operand (the q / k / v projections of a layer) stay neighbours part by part, which is what the
+    // planner's placement looks for.
+    std::vector<float*> c_part(count, nullptr), b_part(count, nullptr);
+    std::vector<long> c_stride(count, 0);
+    float* cursor = workspace;
+    int f = 0, blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (parts[i] < 2) continue;
+        const athena_wgrad_item& it = items[i];
+        const long nc = ((long)it.M * it.N + 3) / 4 * 4, nb = it.bsum ? ((long)it.N + 3) / 4 * 4 : 0;
+        c_part[i] = cursor;
+        b_part[i] = it.bsum ? cursor + nc : nullptr;
+        c_stride[i] = nc + nb;
+        cursor += (long)parts[i] * (nc + nb);
+        athena_wgrad_fold& fc = folds[f++];
+        fc.dst = it.C; fc.src = c_part[i]; fc.n = (long)it.M * it.N; fc.part_stride = nc + nb; fc.parts = parts[i];
+        fc.first_block = blocks;
+        blocks += (int)((fc.n + WG_FOLD_CHUNK - 1) / WG_FOLD_CHUNK);
+        if (it.bsum) {
+            athena_wgrad_fold& fb = folds[f++];
+            fb.dst = it.bsum; fb.src = b_part[i]; fb.n = it.N; fb.part_stride = nc + nb; fb.parts = parts[i];
+            fb.first_block = blocks;
+            blocks += (int)((fb.n + WG_FOLD_CHUNK - 1) / WG_FOLD_CHUNK);
+        }
+    }
+    int o = 0;
+    for (int p = 0; p < 8; ++p)
+        for (int i = 0; i < count; ++i) {
+            if (p >= parts[i]) continue;
+            athena_wgrad_item it = items[i];
+            if (parts[i] > 1) {
+                // equal row ranges, multiples of 8 rows (the last one takes what is left)
+                const long rows = ((long)items[i].K + parts[i] - 1) / parts[i];
+                const long step = (rows + 7) / 8 * 8;
+                const long r0 = std::min((long)p * step, (long)items[i].K);
+                const long r1 = p + 1 == parts[i] ? (long)items[i].K : std::min(r0 + step, (long)items[i].K);
+                if (r1 <= r0) {
+                    // (cannot happen with parts of >= 512 rows; a part without rows would leave its
+                    // partial result unwritten)
+                    ATHENA_REQUIRE(false, ATHENA_E_SHAPE, "athena_gemm_wgrad_split: item %d: empty part", i);
+                }
+                it.A = (const char*)items[i].A + r0 * items[i].lda * 2;
+                it.B = (const char*)items[i].B + r0 * items[i].ldb * 2;
+                it.K = (int32_t)(r1 - r0);
+                it.C = c_part[i] + (long)p * c_stride[i];
+                it.bsum = b_part[i] ? b_part[i] + (long)p * c_stride[i] : nullptr;
+            }
+            out_items[o++] = it;
+        }
+    if (fold_blocks) *fold_blocks = blocks;
+    return ATHENA_OK;
+}
+
+// dst[j] = sum over parts of src[part * stride + j]: one workgroup per WG_FOLD_CHUNK floats of a fold
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const athena_wgrad_fold* __restrict__ folds, int count) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (folds[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const athena_wgrad_fold f = folds[lo];
+    const long base = (long)((int)blockIdx.x - f.first_block) * WG_FOLD_CHUNK;
+    const bool vec = (((uintptr_t)f.dst | (uintptr_t)f.src) & 15) == 0 && (f.part_stride & 3) == 0;
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < WG_FOLD_CHUNK / 1024; ++i) {
+            const long j = base + (i * 256 + threadIdx.x) * 4;
+            if (j + 4 <= f.n) {
+                float4 acc = *(const float4*)(f.src + j);
+                for (int p = 1; p < f.parts; ++p) {
+                    const float4 v = *(const float4*)(f.src + p * f.part_stride + j);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                *(float4*)(f.dst + j) = acc;
+            } else {
+                for (long jj = j; jj < f.n; ++jj) {
+                    float acc = f.src[jj];
+                    for (int p = 1; p < f.parts; ++p) acc += f.src[p * f.part_stride + jj];
+                    f.dst[jj] = acc;
+                }
+            }
+        }
+    } else {
+        for (long j = base + threadIdx.x; j < min(base + (long)WG_FOLD_CHUNK, (long)f.n); j += 256) {
+            float acc = f.src[j];
+            for (int p = 1; p < f.parts; ++p) acc += f.src[p * f.part_stride + j];
+            f.dst[j] = acc;
+        }
+    }
+}
+
+extern "C" int athena_gemm_wgrad_fold(const athena_wgrad_fold* folds_dev, int count, int blocks, athena_stream_t stream) {
+    ATHENA_REQUIRE(folds_dev && count > 0 && blocks > 0, ATHENA_E_SHAPE, "athena_gemm_wgrad_fold: empty list");
+    ATHENA_LAUNCH(wgrad_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, folds_dev, count);
+    ATHENA_CHECK_LAUNCH("athena_gemm_wgrad_fold");
     return ATHENA_OK;
 }

@@ -388,7 +388,11 @@ class _OneGraphPipelinedStep:
                 works.append(solver._exchange_async(grads[lo:min(lo + step, b)]))
 
         from .layers.fused import _WgradQueue
-        side_tables = solver._rccl is not None and os.environ.get("ATHENA_DP_SIDE_TABLES", "1") != "0"
+        # (ATHENA_DP_SIDE_TABLES=1: each piece's weight-gradient table on the exchange stream instead of
+        # the launch stream.  Not the default: a table whose contractions are split fills the chip by
+        # itself, and beside the backward pass it only takes compute units away from kernels that need
+        # all of them at once.)
+        side_tables = solver._rccl is not None and os.environ.get("ATHENA_DP_SIDE_TABLES", "0") == "1"
         if side_tables and solver._side is None:
             solver._side = torch.cuda.Stream()
         store.collect_cuts = True

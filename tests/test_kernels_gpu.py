@@ -449,10 +449,15 @@ def test_conv3x3s2_large_tile_core(ops, monkeypatch, B, H, W, Cin, Cout):
     assert_close(out, out0.double(), 1e-2, "conv fwd, two cores")
 
 
-def test_gemm_wgrad_table(ops):
+@pytest.mark.parametrize("split", [True, False])
+def test_gemm_wgrad_table(ops, split, monkeypatch):
     """Weight and bias gradients of many Dense layers in one launch of the 256x256 core: shapes that
     fill several tiles, shapes smaller than one, operands that are column blocks of wider matrices,
-    a contraction that is not a multiple of the k-tile."""
+    a contraction that is not a multiple of the k-tile.  The table is far from filling the chip, so
+    with ``split`` its long contractions are cut into parts (the 8000-row one into seven, the
+    2000-row one into two) whose partial products a second launch sums."""
+    monkeypatch.setattr(ops._WgradTables, "split_enabled", split)
+    ops._WgradTables.cache.clear()
     g = torch.Generator().manual_seed(123)
     cd = torch.bfloat16
     shapes = [  # rows, M (in features), N (out features), extra columns of x / dy storage
@@ -473,6 +478,8 @@ def test_gemm_wgrad_table(ops):
         refs.append((Xr.t() @ dYr, dYr.sum(0)))
         keep.append((x_d, dy_d))
     ops.gemm_wgrad_table(problems)
+    entry = next(iter(ops._WgradTables.cache.values()))
+    assert (entry[3] > len(problems) and entry[7] > 0) if split else (entry[3] == len(problems) and entry[7] == 0)
     for (xv, yv, rows, M, N, ldx, ldy, G, gb), (gr, br) in zip(problems, refs):
         assert_close(G, gr, 2e-5, "weight gradient %dx%d over %d rows" % (M, N, rows))
         if gb is not None:
@@ -481,6 +488,7 @@ def test_gemm_wgrad_table(ops):
     first = [p[7].clone() for p in problems]
     ops.gemm_wgrad_table(problems)
     assert all(torch.equal(a, p[7]) for a, p in zip(first, problems))
+    ops._WgradTables.cache.clear()
 
 
 @pytest.mark.parametrize("cd", DTYPES)
