@@ -133,7 +133,7 @@ _SIGNATURES = {
     "athena_conv1_bn_relu6_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_int, c_int, c_int,
                                           _P, _S]),
     "athena_conv1_bn_bwd_workspace_bytes": (c_int64, [c_int]),
-    "athena_conv1_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P,
+    "athena_conv1_bn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P,
                                     _P, _S]),
     "athena_conv3x3s2_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _S]),
     "athena_conv3x3s2_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),

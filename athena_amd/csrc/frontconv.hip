@@ -15,6 +15,8 @@
 //             dw[t][c] = gamma rstd ( T - sb/n S[t] - dgamma/n rstd (sum_u R[t][u] w[u][c] - mean S[t]) ).
 #include "common.h"
 #include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 #define FC_K 9                      // taps
 #define FC_NMOM (FC_K + FC_K * FC_K)
@@ -251,21 +253,17 @@ __device__ __forceinline__ void fc_split(float x, bf16_t& hi, bf16_t& lo) {
     lo = (bf16_t)(x - (float)hi);
 }
 
-template <int NPAIR>
-__global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                          const float* __restrict__ s0, const float* __restrict__ s1,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, int infer, int B,
-                                                          int H, int W, int C, int Ho, int Wo, int ph, int pw,
-                                                          bf16_t* __restrict__ out) {
-    constexpr int CB = 32 * NPAIR;                   // channels per workgroup (blockIdx.y picks the block)
-    constexpr int SROW = CB + 8;                     // padded row of the output staging tile (elements)
-    constexpr int LPR = CB / 8, RPI = 64 / LPR;      // lanes per tile row, rows per store instruction
-    __shared__ float sW[FC_K + 1][CB];               // scaled weights, then the shift
-    __shared__ __attribute__((aligned(16))) bf16_t sO[4][16][SROW];      // one 16-pixel tile per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, li = lane & 15;
-    const int cb = blockIdx.y * CB;
-    for (int i = tid; i < CB; i += 256) {
+// Weight fragments of the matrix-core form (see fc_fwd_mfma_kernel): the CB = 32 * NPAIR channels from
+// ``cb`` on, scaled by rstd * gamma, with the BatchNorm shift as the last contraction slots.  sW is
+// workgroup scratch; all 256 threads take part.
+template <int NPAIR, int NTHREADS = 256>
+__device__ __forceinline__ void fc_weight_frags(const float* __restrict__ w, const float* __restrict__ s0,
+                                                const float* __restrict__ s1, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float eps, int infer, int C, int cb,
+                                                float (&sW)[FC_K + 1][32 * NPAIR], bf16x8_t (&wf)[NPAIR][2]) {
+    constexpr int CB = 32 * NPAIR;
+    const int tid = threadIdx.x, lane = tid & 63, kg = lane >> 4, li = lane & 15;
+    for (int i = tid; i < CB; i += NTHREADS) {
         const int c = cb + i;
         const float mu = s0[c];
         const float rs = infer ? rsqrtf(s1[c] + eps) : s0[C + c];
@@ -276,7 +274,6 @@ __global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restric
     }
     __syncthreads();
     // A-operand fragments: row m = lane & 15 of product j of pair P is channel 32 P + 8 (m >> 2) + 4 j + (m & 3)
-    bf16x8_t wf[NPAIR][2];
 #pragma unroll
     for (int P = 0; P < NPAIR; ++P)
 #pragma unroll
@@ -299,55 +296,101 @@ __global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restric
             }
             wf[P][j] = f;
         }
+}
+
+// the nine input values around a pixel as loaded (address clamped into the image) and the bit
+// mask of those inside it; the mask is applied when the values are used, a trip later
+struct FcTaps { float v[FC_K]; uint32_t ok; };
+__device__ __forceinline__ void fc_fetch_taps(const float* __restrict__ in, int H, int W, int Ho, int Wo, int ph,
+                                              int pw, int pix, FcTaps& t) {
+    const int q = pix / Wo, wo = pix - q * Wo;
+    const int b = q / Ho, ho = q - b * Ho;
+    // addresses first (rows and columns clamped into the image: branch-free and always valid),
+    // then the nine loads back to back
+    uint32_t okm = 0;
+    int idx[FC_K];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * ho - ph + kh;
+        const int hc = min(max(h, 0), H - 1);
+        const uint32_t hok = (h == hc) ? 1u : 0u;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int x = 2 * wo - pw + kw;
+            const int xc = min(max(x, 0), W - 1);
+            idx[kh * 3 + kw] = (b * H + hc) * W + xc;
+            okm |= (hok & ((x == xc) ? 1u : 0u)) << (kh * 3 + kw);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FC_K; ++i) t.v[i] = in[idx[i]];
+    t.ok = okm;
+}
+// the same from the pixel's coordinates (a caller that walks the pixels with a fixed stride keeps them
+// up to date with additions instead of dividing every time); 32-bit offsets from one base
+__device__ __forceinline__ void fc_fetch_taps_at(const float* __restrict__ in, int H, int W, int ph, int pw, int b,
+                                                 int ho, int wo, FcTaps& t) {
+    uint32_t okm = 0;
+    uint32_t idx[FC_K];
+    const int rowbase = b * H;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = 2 * ho - ph + kh;
+        const int hc = min(max(h, 0), H - 1);
+        const uint32_t hok = (h == hc) ? 1u : 0u;
+        const int rb = (rowbase + hc) * W;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int x = 2 * wo - pw + kw;
+            const int xc = min(max(x, 0), W - 1);
+            idx[kh * 3 + kw] = (uint32_t)(rb + xc);
+            okm |= (hok & ((x == xc) ? 1u : 0u)) << (kh * 3 + kw);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FC_K; ++i) t.v[i] = in[idx[i]];
+    t.ok = okm;
+}
+// B-operand fragment of a pixel from its nine taps (kg = lane >> 4: the group of contraction slots)
+__device__ __forceinline__ bf16x8_t fc_tap_frag(const FcTaps& t, int kg) {
+    bf16_t hi[FC_K], lo[FC_K];
+#pragma unroll
+    for (int i = 0; i < FC_K; ++i) fc_split(((t.ok >> i) & 1u) ? t.v[i] : 0.f, hi[i], lo[i]);
+    bf16x8_t f;
+    if (kg < 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = kg == 2 ? lo[e] : hi[e];
+    } else {
+        const bf16_t one = (bf16_t)1.f, z = (bf16_t)0.f;
+        f = (bf16x8_t){hi[8], hi[8], lo[8], one, one, z, z, z};
+    }
+    return f;
+}
+
+template <int NPAIR>
+__global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ s0, const float* __restrict__ s1,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, int infer, int B,
+                                                          int H, int W, int C, int Ho, int Wo, int ph, int pw,
+                                                          bf16_t* __restrict__ out) {
+    constexpr int CB = 32 * NPAIR;                   // channels per workgroup (blockIdx.y picks the block)
+    constexpr int SROW = CB + 8;                     // padded row of the output staging tile (elements)
+    constexpr int LPR = CB / 8, RPI = 64 / LPR;      // lanes per tile row, rows per store instruction
+    __shared__ float sW[FC_K + 1][CB];               // scaled weights, then the shift
+    __shared__ __attribute__((aligned(16))) bf16_t sO[4][16][SROW];      // one 16-pixel tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, li = lane & 15;
+    const int cb = blockIdx.y * CB;
+    bf16x8_t wf[NPAIR][2];
+    fc_weight_frags<NPAIR>(w, s0, s1, gamma, beta, eps, infer, C, cb, sW, wf);
     // the launch covers whole 64-pixel blocks only (the host sends a ragged tail to the vector
     // kernel): no store below is predicated, so the wait for the next trip's taps can leave this
     // trip's stores in flight
     const int nblk = (B * Ho * Wo) / 64;
-    // the nine input values around a pixel as loaded (address clamped into the image) and the bit
-    // mask of those inside it; the mask is applied when the values are used, a trip later
-    struct Taps { float v[FC_K]; uint32_t ok; };
-    auto fetch = [&](int blk, Taps& t) {
-        const int pix = blk * 64 + wave * 16 + li;
-        const int q = pix / Wo, wo = pix - q * Wo;
-        const int b = q / Ho, ho = q - b * Ho;
-        // addresses first (rows and columns clamped into the image: branch-free and always valid),
-        // then the nine loads back to back
-        uint32_t okm = 0;
-        int idx[FC_K];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int h = 2 * ho - ph + kh;
-            const int hc = min(max(h, 0), H - 1);
-            const uint32_t hok = (h == hc) ? 1u : 0u;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int x = 2 * wo - pw + kw;
-                const int xc = min(max(x, 0), W - 1);
-                idx[kh * 3 + kw] = (b * H + hc) * W + xc;
-                okm |= (hok & ((x == xc) ? 1u : 0u)) << (kh * 3 + kw);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < FC_K; ++i) t.v[i] = in[idx[i]];
-        t.ok = okm;
-    };
-    // B-operand fragment of a pixel from its nine taps
-    auto tap_frag = [&](const Taps& t) {
-        bf16_t hi[FC_K], lo[FC_K];
-#pragma unroll
-        for (int i = 0; i < FC_K; ++i) fc_split(((t.ok >> i) & 1u) ? t.v[i] : 0.f, hi[i], lo[i]);
-        bf16x8_t f;
-        if (kg < 3) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = kg == 2 ? lo[e] : hi[e];
-        } else {
-            const bf16_t one = (bf16_t)1.f, z = (bf16_t)0.f;
-            f = (bf16x8_t){hi[8], hi[8], lo[8], one, one, z, z, z};
-        }
-        return f;
-    };
+    auto fetch = [&](int blk, FcTaps& t) { fc_fetch_taps(in, H, W, Ho, Wo, ph, pw, blk * 64 + wave * 16 + li, t); };
+    auto tap_frag = [&](const FcTaps& t) { return fc_tap_frag(t, kg); };
     // one trip: the wave's 16 pixels x CB channels from the taps fetched a trip earlier
-    auto emit = [&](int blk, const Taps& t) {
+    auto emit = [&](int blk, const FcTaps& t) {
         const bf16x8_t pf = tap_frag(t);
         bf16_t* so = &sO[wave][0][0];
 #pragma unroll
@@ -381,7 +424,7 @@ __global__ __launch_bounds__(256) void fc_fwd_mfma_kernel(const float* __restric
     // of two register sets (no copies: a copy would wait for the loads AND for the stores issued
     // after them).  The fetch is unconditional -- the last trip re-reads its own block -- so the
     // number of outstanding loads is the same on every path.
-    Taps t0, t1;
+    FcTaps t0, t1;
     int blk = blockIdx.x;
     if (blk >= nblk) return;
     fetch(blk, t0);
@@ -587,6 +630,188 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const float* __restr
     for (int i = threadIdx.x; i < (FC_K + 1) * C; i += 256) dst[i] = red[i];
 }
 
+// The same reduction on the matrix cores, reading the gradient alone.
+//   * The relu6 gate is worked out again instead of read off the stored activation: the forward pass's
+//     contraction (fc_fwd_mfma_kernel: channels x pixels from the split weights and taps, bit for bit
+//     the value that was clamped and stored) gives the pre-clamp BatchNorm output d, and the gate is
+//     [0 < d < 6] -- what [0 < stored < 6] says, since a stored value is never rounded across 0 or 6.
+//   * The sums over pixels T[t][c] = sum_p a[p][t] g[p][c] are products too: a wave's 16 pixels are the
+//     contraction of one 16x16x16 product per 16 channels, [channels x pixels] [pixels x (9 taps, 1)],
+//     with the fp32 taps split into two bf16 halves (two products into one accumulator).  Both operands
+//     have the pixel as the slow index where they are made (a lane has 8 channels of ONE pixel, and
+//     that pixel's taps), so the wave lays them down in LDS and reads them back transposed.  Sixteen
+//     accumulator registers per lane instead of 160, no multiply-adds on the vector ALUs.
+// A workgroup takes up to 256 channels, so the taps of a pixel are fetched and split once for all of
+// them.  Lane (li, kg) of a wave has pixel li of the wave's 16 and, per pair P, the eight channels
+// cb + 32 P + 8 kg .. + 7: the layout of the gate's product and of a 16-byte piece of the gradient.
+// Slab layout as fc_bwd_reduce_kernel: partial[blockIdx.x][t][c]; blockIdx.y picks the block of
+// 32 * NPAIR channels.
+typedef short fc_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ fc_s4 fc_read_tr(const bf16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((fc_s4 __attribute__((address_space(3)))*)p);
+}
+
+template <int NPAIR, int NW>
+__global__ __launch_bounds__(64 * NW) void fc_bwd_reduce_mfma_kernel(const float* __restrict__ in,
+                                                                 const bf16_t* __restrict__ g,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ mean_rstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int B, int H, int W,
+                                                                 int C, int Ho, int Wo, int ph, int pw,
+                                                                 float* __restrict__ partial) {
+    constexpr int CB = 32 * NPAIR;
+    constexpr int GROW = CB + 8;                     // padded rows (elements) of the gradient tile
+    constexpr int TROW = 24;                         // and of the two tap tiles (16 columns used)
+    constexpr int RED_BYTES = NW * (FC_K + 1) * CB * 4, TILE_BYTES = NW * 16 * GROW * 2;
+    __shared__ float sW[FC_K + 1][CB];
+    __shared__ __attribute__((aligned(16))) bf16x8_t sF[NPAIR][2][64];       // the weight fragments, by lane
+    // the waves' gradient tiles; after the loop the same bytes hold the waves' sums
+    __shared__ __attribute__((aligned(16))) char sGR[RED_BYTES > TILE_BYTES ? RED_BYTES : TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) bf16_t sT[NW][2][16 * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, li = lane & 15;
+    const int cb = blockIdx.y * CB;
+    {
+        bf16x8_t wf[NPAIR][2];
+        fc_weight_frags<NPAIR, 64 * NW>(w, mean_rstd, nullptr, gamma, beta, 0.f, 0, C, cb, sW, wf);
+        if (wave == 0) {
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) {
+                sF[P][0][lane] = wf[P][0];
+                sF[P][1][lane] = wf[P][1];
+            }
+        }
+        __syncthreads();
+    }
+    const int npix = B * Ho * Wo;
+    const int nblk = (npix + 16 * NW - 1) / (16 * NW);
+    // acc[rb][r]: channel cb + 16 rb + 4 kg + r, column li (taps 0..8, then the plain sum)
+    f32x4_t acc[2 * NPAIR];
+#pragma unroll
+    for (int rb = 0; rb < 2 * NPAIR; ++rb) acc[rb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // A trip = the wave's 16 pixels x CB channels.  Its taps are requested a trip ahead (two register
+    // sets); its NPAIR pieces of the gradient sit in gq, and each is requested again for the next trip
+    // at the moment it is used, so a lane always has NPAIR 16-byte loads in flight.  A block beyond the
+    // last one and a pixel beyond the last one re-read valid addresses and count for nothing.
+    struct Trip { FcTaps t; float one; int pc; };
+    // the lane's pixel walks through the image with a fixed stride: its coordinates (b, ho, wo) are
+    // advanced by that stride's own coordinates with carries, no division in the loop
+    const int step_pix = gridDim.x * 16 * NW;
+    const int d_wo = step_pix % Wo, d_q = step_pix / Wo, d_ho = d_q % Ho, d_b = d_q / Ho;
+    int c_pix = blockIdx.x * 16 * NW + wave * 16 + li;
+    int c_wo = c_pix % Wo, c_ho = (c_pix / Wo) % Ho, c_b = c_pix / Wo / Ho;
+    auto fetch_next = [&](Trip& r) {
+        // (the walker's current position, then one step on)
+        const bool live = c_pix < npix;
+        r.pc = live ? c_pix : npix - 1;
+        fc_fetch_taps_at(in, H, W, ph, pw, live ? c_b : B - 1, live ? c_ho : Ho - 1, live ? c_wo : Wo - 1, r.t);
+        if (!live) r.t.ok = 0;
+        r.one = live ? 1.f : 0.f;
+        c_pix += step_pix;
+        c_wo += d_wo;
+        const int cw = c_wo >= Wo ? 1 : 0;
+        c_wo -= cw ? Wo : 0;
+        c_ho += d_ho + cw;
+        const int ch = c_ho >= Ho ? 1 : 0;
+        c_ho -= ch ? Ho : 0;
+        c_b += d_b + ch;
+    };
+    bf16x8_t gq[NPAIR];
+    bf16_t* myG = (bf16_t*)sGR + wave * 16 * GROW;
+    bf16_t* myT0 = sT[wave][0];
+    bf16_t* myT1 = sT[wave][1];
+    // transposed reads: the 16 lanes of group kg take rows 4 kg .. 4 kg + 3, lane li column (block) li
+    const int tr_row = 4 * kg + (li >> 2), tr_col = 4 * (li & 3);
+    auto consume = [&](const Trip& r, const Trip& next) {
+        const bf16x8_t pf = fc_tap_frag(r.t, kg);
+        // the pixel's row of the two tap tiles: hi halves and the 1 of the plain sum | lo halves
+        if (kg == 0) {
+            bf16x8_t h0, h1, l0, l1;
+            const bf16_t z = (bf16_t)0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                bf16_t hi, lo;
+                fc_split(((r.t.ok >> e) & 1u) ? r.t.v[e] : 0.f, hi, lo);
+                h0[e] = hi;
+                l0[e] = lo;
+                h1[e] = z;
+                l1[e] = z;
+            }
+            bf16_t hi8, lo8;
+            fc_split(((r.t.ok >> 8) & 1u) ? r.t.v[8] : 0.f, hi8, lo8);
+            h1[0] = hi8;
+            l1[0] = lo8;
+            h1[1] = (bf16_t)r.one;
+            *(bf16x8_t*)(myT0 + li * TROW) = h0;
+            *(bf16x8_t*)(myT0 + li * TROW + 8) = h1;
+            *(bf16x8_t*)(myT1 + li * TROW) = l0;
+            *(bf16x8_t*)(myT1 + li * TROW + 8) = l1;
+        }
+        const bf16_t* gnext = g + (long)next.pc * C + cb + 8 * kg;
+#pragma unroll
+        for (int P = 0; P < NPAIR; ++P) {
+            const bf16x8_t gc = gq[P];
+            gq[P] = *(const bf16x8_t*)(gnext + 32 * P);
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sF[P][0][lane], pf, zero, 0, 0, 0);
+            const f32x4_t d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sF[P][1][lane], pf, zero, 0, 0, 0);
+            bf16x8_t gv;
+            const bf16_t z = (bf16_t)0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gv[e] = (d0[e] > 0.f && d0[e] < 6.f) ? gc[e] : z;
+                gv[4 + e] = (d1[e] > 0.f && d1[e] < 6.f) ? gc[4 + e] : z;
+            }
+            *(bf16x8_t*)(myG + li * GROW + 32 * P + 8 * kg) = gv;
+        }
+        // (one wave: its LDS operations are carried out in order, the reads below see the writes above)
+        const fc_s4 bh = fc_read_tr(myT0 + tr_row * TROW + tr_col);
+        const fc_s4 bl = fc_read_tr(myT1 + tr_row * TROW + tr_col);
+#pragma unroll
+        for (int rb = 0; rb < 2 * NPAIR; ++rb) {
+            const fc_s4 af = fc_read_tr(myG + tr_row * GROW + 16 * rb + tr_col);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, bh, acc[rb], 0, 0, 0);
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af, bl, acc[rb], 0, 0, 0);
+        }
+    };
+    {
+        const int stride = gridDim.x;
+        int blk = blockIdx.x;
+        Trip cur, nxt;
+        if (blk < nblk) {
+            fetch_next(cur);
+            const bf16_t* g0 = g + (long)cur.pc * C + cb + 8 * kg;
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) gq[P] = *(const bf16x8_t*)(g0 + 32 * P);
+            for (; blk < nblk; blk += stride) {
+                // (the weight fragments are read from LDS every trip: kept in registers across trips
+                // they would cost the second wave per SIMD)
+                asm volatile("" ::: "memory");
+                fetch_next(nxt);
+                consume(cur, nxt);
+                cur = nxt;
+            }
+        }
+    }
+    // the four waves through LDS (the products have summed over the pixels); the tiles are done with
+    __syncthreads();
+    float (*red)[FC_K + 1][CB] = (float (*)[FC_K + 1][CB])sGR;
+    if (li <= FC_K) {
+#pragma unroll
+        for (int rb = 0; rb < 2 * NPAIR; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][li][16 * rb + 4 * kg + e] = acc[rb][e];
+    }
+    __syncthreads();
+    float* dst = partial + (long)blockIdx.x * (FC_K + 1) * C;
+    for (int i = tid; i < (FC_K + 1) * CB; i += 64 * NW) {
+        const int t = i / CB, c = i - t * CB;
+        float v = (red[0][t][c] + red[1][t][c]) + (red[2][t][c] + red[3][t][c]);
+        if (NW == 8) v += (red[4][t][c] + red[5][t][c]) + (red[6][t][c] + red[7][t][c]);
+        dst[t * C + cb + c] = v;
+    }
+}
+
 // sums the slabs: workgroup = 64 entries (t, c) x 4 waves, each wave takes a quarter of the slabs
 __global__ __launch_bounds__(256) void fc_bwd_fold_kernel(const float* __restrict__ partial, int nblk, int nent,
                                                           double* __restrict__ tot) {
@@ -645,9 +870,9 @@ extern "C" int64_t athena_conv1_bn_bwd_workspace_bytes(int Cout) {
 
 extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* relu6_out, const float* w_hwio,
                                    const double* moments,
-                                   const float* mean_rstd, const float* gamma, int B, int H, int W, int Cout,
-                                   int dtype, void* workspace, int64_t workspace_bytes, float* dw_hwio, float* dgamma,
-                                   float* dbeta, athena_stream_t stream) {
+                                   const float* mean_rstd, const float* gamma, const float* beta, int B, int H, int W,
+                                   int Cout, int dtype, void* workspace, int64_t workspace_bytes, float* dw_hwio,
+                                   float* dgamma, float* dbeta, athena_stream_t stream) {
     int rc = fc_check("athena_conv1_bn_bwd", B, H, W, Cout, dtype);
     if (rc) return rc;
     ATHENA_REQUIRE(in && g && w_hwio && moments && mean_rstd && gamma && workspace && dw_hwio && dgamma && dbeta,
@@ -667,6 +892,30 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* r
     hipStream_t s = (hipStream_t)stream;
     const size_t shm = sizeof(float) * (FC_K + 1) * Cout * (Cout / cpt <= 64 ? 4 : 1);
     ATHENA_REQUIRE(!relu6_out || athena_aligned16(relu6_out), ATHENA_E_ALIGN, "athena_conv1_bn_bwd: relu6_out alignment");
+    static const int fc_gate = getenv("ATHENA_FC_GATE") ? atoi(getenv("ATHENA_FC_GATE")) : 8;
+    static const int fc_wgs = getenv("ATHENA_FC_WGS") ? atoi(getenv("ATHENA_FC_WGS")) : 256;
+    if (relu6_out && beta && dtype == ATHENA_BF16 && Cout % 64 == 0 && (Cout <= 256 || Cout % 256 == 0) && fc_gate > 0) {
+        // the gate worked out again instead of read: up to 256 channels per workgroup, eight waves of
+        // 16 pixels per trip (one workgroup per CU and slab; four waves for narrow layers)
+        const int cbw = Cout < 256 ? Cout : 256, ncb = Cout / cbw;
+        const int nw = (cbw == 256 && fc_gate == 8) ? 8 : 4;
+        long nb = (npix + 16 * nw - 1) / (16 * nw);
+        blocks = std::max(1L, std::min(std::min(nb, (long)FC_BWD_BLOCKS), (long)(fc_wgs * (nw == 8 ? 1 : 2) / ncb)));
+        const dim3 grid((unsigned)blocks, (unsigned)ncb);
+#define FC_BWD_MFMA(NP, NWV)                                                                                   \
+    ATHENA_LAUNCH((fc_bwd_reduce_mfma_kernel<NP, NWV>), grid, dim3(64 * NWV), 0, s, in, (const bf16_t*)g, w_hwio, \
+                  mean_rstd, gamma, beta, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace)
+        switch (cbw / 32) {
+            case 2: FC_BWD_MFMA(2, 4); break;
+            case 4: FC_BWD_MFMA(4, 4); break;
+            case 6: FC_BWD_MFMA(6, 4); break;
+            default:
+                if (nw == 8) FC_BWD_MFMA(8, 8);
+                else FC_BWD_MFMA(8, 4);
+                break;
+        }
+#undef FC_BWD_MFMA
+    } else {
 #define FC_BWD(TT, CC)                                                                                          \
     ATHENA_LAUNCH((fc_bwd_reduce_kernel<TT, CC>), dim3((unsigned)blocks), dim3(256), shm, s, in, (const TT*)g, \
                        (const TT*)relu6_out, B, H, W, Cout, Ho, Wo, ph, pw, (float*)workspace)
@@ -678,6 +927,7 @@ extern "C" int athena_conv1_bn_bwd(const float* in, const void* g, const void* r
         else FC_BWD(float, 8);
     }
 #undef FC_BWD
+    }
     const int nent = (FC_K + 1) * Cout;
     double* tot = (double*)((char*)workspace + sizeof(float) * (size_t)FC_BWD_BLOCKS * nent);   // 8-byte aligned
     ATHENA_LAUNCH(fc_bwd_fold_kernel, dim3((nent + 63) / 64), dim3(256), 0, s, (const float*)workspace, (int)blocks,

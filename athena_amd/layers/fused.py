@@ -759,7 +759,7 @@ class XNetFn(torch.autograd.Function):
             # gated gradient; the relu6 gate is read off a1 while da1 is streamed through
             ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
             ops.conv1_bn_bwd(x0, da1, net.conv1.kernel, mom1, mr1, net.bn1.gamma, B, T, Fd, C, net.conv1.kernel.grad,
-                             net.bn1.gamma.grad, net.bn1.beta.grad, relu6_out=a1)
+                             net.bn1.gamma.grad, net.bn1.beta.grad, relu6_out=a1, beta=net.bn1.beta)
         else:
             ops.conv3x3s2_dgrad(dc2, w_hwio, da1, B, T1, F1, C, C)
             dc1 = torch.empty_like(c1)

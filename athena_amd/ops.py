@@ -572,8 +572,11 @@ def conv1_bn_relu6_fwd(x, w_hwio, s0, s1, gamma, beta, eps, infer, B, H, W, Cout
                "athena_conv1_bn_relu6_fwd")
 
 
-def conv1_bn_bwd(x, g, w_hwio, moments, mean_rstd, gamma, B, H, W, Cout, dw, dgamma, dbeta, relu6_out=None):
+def conv1_bn_bwd(x, g, w_hwio, moments, mean_rstd, gamma, B, H, W, Cout, dw, dgamma, dbeta, relu6_out=None, beta=None):
+    """``relu6_out``: the gate is applied here; with ``beta`` too it is worked out again instead of read."""
     lib = _lib.load()
+    if beta is not None and (beta.dtype != torch.float32 or beta.numel() < Cout):
+        raise RuntimeError("athena_amd.conv1_bn_bwd: beta must be fp32 [Cout]")
     if relu6_out is not None and (relu6_out.numel() != g.numel() or relu6_out.dtype != g.dtype):
         raise RuntimeError("athena_amd.conv1_bn_bwd: relu6_out must match g")
     if x.dtype != torch.float32 or x.numel() != B * H * W or g.numel() != B * same_out(H) * same_out(W) * Cout or \
@@ -581,7 +584,7 @@ def conv1_bn_bwd(x, g, w_hwio, moments, mean_rstd, gamma, B, H, W, Cout, dw, dga
             mean_rstd.numel() < 2 * Cout or dgamma.numel() < Cout or dbeta.numel() < Cout:
         raise RuntimeError("athena_amd.conv1_bn_bwd: bad operands")
     ws = splitk_workspace(x.device)
-    _lib.check(lib.athena_conv1_bn_bwd(_ptr(x), _ptr(g), _ptr(relu6_out), _ptr(w_hwio), _ptr(moments), _ptr(mean_rstd), _ptr(gamma), B,
+    _lib.check(lib.athena_conv1_bn_bwd(_ptr(x), _ptr(g), _ptr(relu6_out), _ptr(w_hwio), _ptr(moments), _ptr(mean_rstd), _ptr(gamma), _ptr(beta), B,
                                        H, W, Cout, dt(g), ws.data_ptr(), ws.numel(), _ptr(dw), _ptr(dgamma),
                                        _ptr(dbeta), _stream()), "athena_conv1_bn_bwd")
 

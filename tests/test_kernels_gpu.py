@@ -314,7 +314,8 @@ def test_mha_fully_masked_row_is_uniform_bf16(ops):
 
 
 @pytest.mark.parametrize("cd", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 13, 10, 32), (3, 40, 16, 64), (1, 7, 5, 8), (2, 50, 21, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 13, 10, 32), (3, 40, 16, 64), (1, 7, 5, 8), (2, 50, 21, 256), (2, 61, 30, 128),
+                                     (1, 33, 18, 512)])
 def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
     """One-channel Conv2D -> BatchNorm (batch statistics) -> relu6 without the pre-activation tensor,
     forward and the three parameter gradients, against autograd on the unfused fp64 chain."""
@@ -364,6 +365,15 @@ def test_conv1_bn_relu6_fused(ops, cd, B, H, W, C):
     ops.conv1_bn_bwd(xd, to_cd(dy, cd), wd, mom, mr, gd, B, H, W, C, dw2, dg2, db2, relu6_out=out_train)
     assert_close(db2, beta.grad, 2e-5 if cd == torch.float32 else 2e-2, "dbeta (gate inside)")
     assert_close(dw2, w.grad, 5e-5 if cd == torch.float32 else 2e-2, "dw (gate inside)")
+    # and with the gate worked out again from the layer's parameters instead of read (bf16 and whole
+    # blocks of 64 channels take that path; elsewhere ``beta`` changes nothing): the same gate, so the
+    # same sums up to the order of the additions
+    dw3, dg3, db3 = torch.empty_like(dw), torch.empty_like(dg), torch.empty_like(db)
+    ops.conv1_bn_bwd(xd, to_cd(dy, cd), wd, mom, mr, gd, B, H, W, C, dw3, dg3, db3, relu6_out=out_train, beta=bd)
+    assert_close(db3, db2.double(), 1e-5, "dbeta (gate worked out again)")
+    assert_close(dg3, dg2.double(), 2e-4, "dgamma (gate worked out again)")
+    assert_close(dw3, dw2.double(), 2e-4, "dw (gate worked out again)")
+    assert_close(dw3, w.grad, 5e-5 if cd == torch.float32 else 2e-2, "dw (gate worked out again, against autograd)")
     # inference form: moving statistics
     mm = (torch.randn(C, generator=g) * 0.1).to(dev())
     mv = (torch.rand(C, generator=g) + 0.5).to(dev())
