@@ -9,7 +9,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
                     c_size_t, c_uint32, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libathena_hip.so")
+# (ATHENA_HIP_LIB names another build of the library, e.g. to compare two kernels on one machine)
+LIB_PATH = os.environ.get("ATHENA_HIP_LIB") or os.path.join(_HERE, "lib", "libathena_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU6, ACT_GELU, ACT_MUL_DGELU, ACT_MUL_DRELU6 = 0, 1, 2, 3, 4

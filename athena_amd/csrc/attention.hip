@@ -9,6 +9,7 @@
 #include "common.h"
 #include "attention_mfma.h"
 #include <initializer_list>
+#include <cstdlib>
 
 #define ATT_TILE 32        // rows of the streamed side per LDS tile
 #define ATT_BLOCK 128      // threads per block
@@ -319,10 +320,11 @@ extern "C" int athena_mha_fwd(const void* q, const void* k, const void* v, int l
     hipStream_t s = (hipStream_t)stream;
     const int rows = Tq;
     if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo}, {q, k, v, out})) {
-        ATHENA_REQUIRE((long)B * h <= 65535, ATHENA_E_SHAPE, "athena_mha_fwd: B*h too large");
-        const dim3 grid((Tq + AM_ROWS - 1) / AM_ROWS, B * h);
+        const long heads8 = ((long)B * h + 7) / 8 * 8;
+        ATHENA_REQUIRE(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS) < (1L << 31), ATHENA_E_SHAPE, "athena_mha_fwd: too many blocks");
+        const dim3 grid((unsigned)(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS)));
         MHA_MFMA_DISPATCH(mha_fwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse);
+                          key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse, B * h);
         ATHENA_CHECK_LAUNCH("athena_mha_fwd");
         return ATHENA_OK;
     }
@@ -347,13 +349,25 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
     const long total = (long)B * h * Tq;
     dim3 gd((unsigned)((total + 255) / 256));
     if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo, lddq, lddk, lddv}, {q, k, v, out, dout, dq, dk_, dv})) {
-        ATHENA_REQUIRE((long)B * h <= 65535, ATHENA_E_SHAPE, "athena_mha_bwd: B*h too large");
-        const dim3 gq((Tq + AM_ROWS - 1) / AM_ROWS, B * h), gk((Tk + AM_ROWS - 1) / AM_ROWS, B * h);
-        MHA_MFMA_DISPATCH(mha_bwd_dq_mfma_kernel, gq, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dq, lddq);
-        MHA_MFMA_DISPATCH(mha_bwd_dkv_mfma_kernel, gk, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dk_,
-                          (bf16_t*)dv, lddk, lddv);
+        const long heads8 = ((long)B * h + 7) / 8 * 8;
+        const long per_head = (Tq + AM_ROWS - 1) / AM_ROWS + (Tk + AM_ROWS - 1) / AM_ROWS;
+        ATHENA_REQUIRE(heads8 * per_head < (1L << 31), ATHENA_E_SHAPE, "athena_mha_bwd: too many blocks");
+        static const bool split = getenv("ATHENA_MHA_BWD_SPLIT") && atoi(getenv("ATHENA_MHA_BWD_SPLIT")) != 0;
+        if (split) {
+            const dim3 gk((unsigned)(heads8 * ((Tk + AM_ROWS - 1) / AM_ROWS))), gq((unsigned)(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS)));
+            MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, gk, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                              key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
+                              (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 1);
+            MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, gq, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                              key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
+                              (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 2);
+            ATHENA_CHECK_LAUNCH("athena_mha_bwd");
+            return ATHENA_OK;
+        }
+        const dim3 grid((unsigned)(heads8 * per_head));
+        MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
+                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
+                          (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 0);
         ATHENA_CHECK_LAUNCH("athena_mha_bwd");
         return ATHENA_OK;
     }

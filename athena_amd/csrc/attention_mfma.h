@@ -101,23 +101,36 @@ __device__ __forceinline__ float att_key_bias(const uint8_t* __restrict__ key_ma
     return (key_mask && key_mask[b * Tk + kj]) ? -1e9f : 0.f;
 }
 
+// Workgroup -> (block w of nW, head): the launch is one-dimensional and consecutive workgroup ids go to
+// the eight XCDs in turn, each with an L2 of its own, so the nW workgroups of a head are given ids
+// that differ by multiples of eight: they run on one XCD at about the same time and the head's
+// operands come through that one L2 once.  The grid is nW * roundup(heads, 8); false = padding.
+__device__ __forceinline__ bool att_xcd_map(int nW, int heads, int& w, int& head) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    head = (slot / nW) * 8 + xcd;
+    w = slot - (slot / nW) * nW;
+    return head < heads;
+}
+
 // ---------------------------------------------------------------- forward
 template <int DK, bool CAUSAL>
 __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                            const uint8_t* __restrict__ key_mask, int causal, int h,
                                                            int Tq, int Tk, float scale, bf16_t* __restrict__ out,
-                                                           int ldo, float* __restrict__ lse) {
+                                                           int ldo, float* __restrict__ lse, int heads) {
     constexpr int KS = DK / 32, NT = DK / 16;
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
     __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
     __shared__ __attribute__((aligned(16))) float sM[2][AM_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    int qblk, head;
+    if (!att_xcd_map((Tq + AM_ROWS - 1) / AM_ROWS, heads, qblk, head)) return;
+    const int b = head / h, hh = head % h;
     const bf16_t* qb = q + (long)b * Tq * ldq + hh * DK;
     const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
     const bf16_t* vb = v + (long)b * Tk * ldv + hh * DK;
-    const int qi = blockIdx.x * AM_ROWS + wave * 16 + li;
+    const int qi = qblk * AM_ROWS + wave * 16 + li;
 
     bf16x8_t qf[KS];
 #pragma unroll
@@ -225,25 +238,32 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 // dQ: a wave owns 16 queries, keys/values streamed.  delta[b,h,i] = sum_c dout[b,i,h,c] * out[b,i,h,c]
 // is worked out here from the dout fragments the kernel holds anyway (the four lanes of a query
 // cover its DK columns between them) and written out for the dK/dV kernel that follows.
+// LDS of a backward workgroup, either role: two stages of two [64][DK] images and of two float rows
+template <int DK>
+struct AttBwdLds {
+    bf16_t a[2][AM_ROWS * DK];      // K (dQ role) or Q (dK/dV role)
+    bf16_t b[2][AM_ROWS * DK];      // V or dout
+    float x[2][AM_ROWS];            // key bias or lse
+    float y[2][AM_ROWS];            // -, or delta
+};
+
 template <int DK, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                              const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
-                                                              const uint8_t* __restrict__ key_mask, int causal, int h,
-                                                              int Tq, int Tk, float scale,
-                                                              const bf16_t* __restrict__ out,
-                                                              const bf16_t* __restrict__ dout, int ldo,
-                                                              const float* __restrict__ lse,
-                                                              float* __restrict__ delta, bf16_t* __restrict__ dq,
-                                                              int lddq) {
+__device__ __forceinline__ void mha_bwd_dq_body(AttBwdLds<DK>& sm, int qblk, int head, const bf16_t* __restrict__ q,
+                                                const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq,
+                                                int ldk, int ldv, const uint8_t* __restrict__ key_mask, int causal,
+                                                int h, int Tq, int Tk, float scale, const bf16_t* __restrict__ out,
+                                                const bf16_t* __restrict__ dout, int ldo,
+                                                const float* __restrict__ lse, float* __restrict__ delta,
+                                                bf16_t* __restrict__ dq, int lddq) {
     constexpr int KS = DK / 32, NT = DK / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) float sM[2][AM_ROWS];
+    bf16_t (&sK)[2][AM_ROWS * DK] = sm.a;
+    bf16_t (&sV)[2][AM_ROWS * DK] = sm.b;
+    float (&sM)[2][AM_ROWS] = sm.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    const int b = head / h, hh = head % h;
     const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
     const bf16_t* vb = v + (long)b * Tk * ldv + hh * DK;
-    const int qi = blockIdx.x * AM_ROWS + wave * 16 + li;
+    const int qi = qblk * AM_ROWS + wave * 16 + li;
     const bool qok = qi < Tq;
 
     bf16x8_t qf[KS], dof[KS];
@@ -337,28 +357,49 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(const bf16_t* __re
     }
 }
 
-// dK, dV: a wave owns 16 keys, queries / dout streamed
+// dK, dV: a wave owns 16 keys, queries / dout streamed.  delta[i] = sum_c dout[i][c] out[i][c] of the
+// streamed queries is worked out here as well, from the pieces of dout the staging loads hold and the
+// same pieces of out (the eight lanes that share a row add up their parts), so this role does not
+// wait for the other one.
+template <int DK>
+__device__ __forceinline__ float att_stage_rowdot(const AttStage<DK>& a, const bf16_t* __restrict__ other, int ld,
+                                                  int row0, int nrows, int tid, int i) {
+    constexpr int NC = DK / 8;
+    const int c = tid + 256 * i;
+    const int row = row0 + c / NC, ch = c % NC;
+    float s = 0.f;
+    if (row < nrows) {
+        const bf16x8_t o = __builtin_bit_cast(bf16x8_t, *(const uint4*)(other + (long)row * ld + ch * 8));
+        const bf16x8_t d = __builtin_bit_cast(bf16x8_t, a.r[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)d[e] * (float)o[e];
+    }
+    // the NC lanes of a row are consecutive
+#pragma unroll
+    for (int o = 1; o < NC; o <<= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+
 template <int DK, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                               const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
-                                                               const uint8_t* __restrict__ key_mask, int causal, int h,
-                                                               int Tq, int Tk, float scale,
-                                                               const bf16_t* __restrict__ dout, int ldo,
-                                                               const float* __restrict__ lse,
-                                                               const float* __restrict__ delta, bf16_t* __restrict__ dk_,
-                                                               bf16_t* __restrict__ dv, int lddk, int lddv) {
-    constexpr int KS = DK / 32, NT = DK / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sQ[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t sO[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) float sL[2][AM_ROWS];
-    __shared__ __attribute__((aligned(16))) float sD[2][AM_ROWS];
+__device__ __forceinline__ void mha_bwd_dkv_body(AttBwdLds<DK>& sm, int kblk, int head, const bf16_t* __restrict__ q,
+                                                 const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq,
+                                                 int ldk, int ldv, const uint8_t* __restrict__ key_mask, int causal,
+                                                 int h, int Tq, int Tk, float scale, const bf16_t* __restrict__ out,
+                                                 const bf16_t* __restrict__ dout, int ldo,
+                                                 const float* __restrict__ lse, bf16_t* __restrict__ dk_,
+                                                 bf16_t* __restrict__ dv, int lddk, int lddv) {
+    constexpr int KS = DK / 32, NT = DK / 16, NC = DK / 8, NP = AM_ROWS * NC / 256;
+    bf16_t (&sQ)[2][AM_ROWS * DK] = sm.a;
+    bf16_t (&sO)[2][AM_ROWS * DK] = sm.b;
+    float (&sL)[2][AM_ROWS] = sm.x;
+    float (&sD)[2][AM_ROWS] = sm.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-    const int b = blockIdx.y / h, hh = blockIdx.y % h;
+    const int b = head / h, hh = head % h;
     const bf16_t* qb = q + (long)b * Tq * ldq + hh * DK;
     const bf16_t* ob = dout + (long)b * Tq * ldo + hh * DK;
+    const bf16_t* yb = out + (long)b * Tq * ldo + hh * DK;
     const float* lb = lse + ((long)b * h + hh) * Tq;
-    const float* db = delta + ((long)b * h + hh) * Tq;
-    const int kj = blockIdx.x * AM_ROWS + wave * 16 + li;
+    const int kj = kblk * AM_ROWS + wave * 16 + li;
     const bool kok = kj < Tk;
 
     bf16x8_t kf[KS], vf[KS];
@@ -376,17 +417,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
     }
 
     AttStage<DK> stQ, stO;
-    float rl = 0.f, rd = 0.f;
+    float rl = 0.f, rd[NP];
     const int nblk = (Tq + AM_ROWS - 1) / AM_ROWS;
     stQ.load(qb, ldq, 0, Tq, tid);
     stO.load(ob, ldo, 0, Tq, tid);
-    if (tid < AM_ROWS) {
-        rl = tid < Tq ? lb[tid] : INFINITY;      // queries past the end: p = exp(-inf) = 0
-        rd = tid < Tq ? db[tid] : 0.f;
-    }
+    if (tid < AM_ROWS) rl = tid < Tq ? lb[tid] : INFINITY;      // queries past the end: p = exp(-inf) = 0
+#pragma unroll
+    for (int i = 0; i < NP; ++i) rd[i] = att_stage_rowdot<DK>(stO, yb, ldo, 0, Tq, tid, i);
     stQ.store(sQ[0], tid);
     stO.store(sO[0], tid);
-    if (tid < AM_ROWS) { sL[0][tid] = rl; sD[0][tid] = rd; }
+    if (tid < AM_ROWS) sL[0][tid] = rl;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        if ((tid + 256 * i) % NC == 0) sD[0][(tid + 256 * i) / NC] = rd[i];
     __syncthreads();
 
     for (int blk = 0; blk < nblk; ++blk) {
@@ -398,8 +441,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
             if (tid < AM_ROWS) {
                 const int i = i0 + AM_ROWS + tid;
                 rl = i < Tq ? lb[i] : INFINITY;
-                rd = i < Tq ? db[i] : 0.f;
             }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) rd[i] = att_stage_rowdot<DK>(stO, yb, ldo, i0 + AM_ROWS, Tq, tid, i);
         }
         // s[it][r] = q(i0 + 16 it + 4 g + r) . k(kj); dp likewise with dout . v
         f32x4_t s[4], dp[4];
@@ -445,7 +489,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
         if (more) {
             stQ.store(sQ[cur ^ 1], tid);
             stO.store(sO[cur ^ 1], tid);
-            if (tid < AM_ROWS) { sL[cur ^ 1][tid] = rl; sD[cur ^ 1][tid] = rd; }
+            if (tid < AM_ROWS) sL[cur ^ 1][tid] = rl;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if ((tid + 256 * i) % NC == 0) sD[cur ^ 1][(tid + 256 * i) / NC] = rd[i];
         }
         __syncthreads();
     }
@@ -460,4 +507,29 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(const bf16_t* __r
             *(bf16x4_t*)(o2 + 16 * nt) = w2;
         }
     }
+}
+
+// One launch for the whole backward pass of the attention: the workgroups of a head are its dK/dV
+// blocks (first: the longer role) and its dQ blocks, side by side on one XCD.
+template <int DK, bool CAUSAL>
+__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+                                                           const uint8_t* __restrict__ key_mask, int causal, int h,
+                                                           int Tq, int Tk, float scale, const bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ dout, int ldo,
+                                                           const float* __restrict__ lse, float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_,
+                                                           bf16_t* __restrict__ dv, int lddq, int lddk, int lddv,
+                                                           int heads, int only) {
+    __shared__ __attribute__((aligned(16))) AttBwdLds<DK> sm;
+    // (``only``: 1 = the dK/dV blocks alone, 2 = the dQ blocks alone -- for measurements)
+    const int nkb = only == 2 ? 0 : (Tk + AM_ROWS - 1) / AM_ROWS, nqb = only == 1 ? 0 : (Tq + AM_ROWS - 1) / AM_ROWS;
+    int w, head;
+    if (!att_xcd_map(nkb + nqb, heads, w, head)) return;
+    if (w < nkb)
+        mha_bwd_dkv_body<DK, CAUSAL>(sm, w, head, q, k, v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, out, dout,
+                                     ldo, lse, dk_, dv, lddk, lddv);
+    else
+        mha_bwd_dq_body<DK, CAUSAL>(sm, w - nkb, head, q, k, v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, out,
+                                    dout, ldo, lse, delta, dq, lddq);
 }

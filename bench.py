@@ -468,7 +468,7 @@ def main():
         a_ms, a_calls, a_launches = kt.total_ms(["attention"])
         if a_calls:
             aa = attention_flops_per_step(wl) * nrep / (a_ms * 1e-3) / 1e12
-            attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_*_mfma_kernel", "bound": "mfma",
+            attn_roof = {"kernel": "mha_fwd_mfma_kernel, mha_bwd_mfma_kernel", "bound": "mfma",
                          "achieved": aa, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": aa / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "attention"),
                          "ms_per_step": a_ms / nrep, "launches_per_step": a_launches // nrep}
