@@ -24,6 +24,10 @@ static int big_tiles_mode() {
     const char* v = getenv("ATHENA_GEMM_BIG");
     return (v && v[0] >= '0' && v[0] <= '2') ? v[0] - '0' : 1;
 }
+static int big_min_k() {
+    static const int k = getenv("ATHENA_GEMM_BIG_MIN_K") ? atoi(getenv("ATHENA_GEMM_BIG_MIN_K")) : 256;
+    return k;
+}
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
@@ -201,7 +205,7 @@ extern "C" int athena_gemm(const athena_gemm_desc* d, athena_stream_t stream) {
     // large plain products ([M,K] x [N,K]^T or [K,M]^T x [K,N], no split) run on the 256x256 core
     const bool big_layout = (!d->trans_a && d->trans_b) || (d->trans_a && !d->trans_b);
     if (big_tiles_enabled() && big_layout && split == 1 &&
-        (big_tiles_forced() || (d->M >= 1024 && d->N >= 1024 && d->K >= 512 && gemm_tiles(d->M, d->N, 256) >= 200)) &&
+        (big_tiles_forced() || (d->M >= 1024 && d->N >= 1024 && d->K >= big_min_k() && gemm_tiles(d->M, d->N, 256) >= 200)) &&
         gemm_big_ok(p, d->in_dtype, d->trans_a != 0))
         return launch_gemm_big(p, d->trans_a != 0, d->trans_b != 0, (hipStream_t)stream);
     rc = launch_gemm(p, d->in_dtype, d->trans_a != 0, d->trans_b != 0, plan.bt, (hipStream_t)stream);

@@ -275,6 +275,15 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         for (int r = 0; r < 4; ++r) { cs[j][r] = 0.f; cq[j][r] = 0.f; }
     const bool bf_out = e.c_dtype == ATHENA_BF16;
     const bool vec_ok = (e.ldc % 4 == 0) && ((((uintptr_t)e.C) & 15) == 0) && (coff % 4 == 0);
+    // the bias of the lane's sixteen columns (zeros without one)
+    float bias_v[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = bn + wn * 64 + j * 16 + 4 * fq + r;
+            bias_v[j][r] = (e.bias && e.atomic != 2 && n < p.N) ? e.bias[n] : 0.f;
+        }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = bm + wm * 128 + i * 16 + fr;
@@ -292,7 +301,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
             }
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha;
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * e.alpha + bias_v[j][r];
             if (e.colsum) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -415,7 +424,8 @@ template <class AMap>
 static inline bool gemm_big_ok(const GemmProblem<AMap>& p, int in_dtype, bool ta) {
     const Epilogue& e = p.epi;
     if (in_dtype != ATHENA_BF16) return false;
-    if (e.bias || e.C_pre || e.aux || e.act != ATHENA_ACT_NONE || e.drop_thresh || e.accum || e.atomic == 1) return false;
+    if (e.C_pre || e.aux || e.act != ATHENA_ACT_NONE || e.drop_thresh || e.accum || e.atomic == 1) return false;
+    if (e.bias && e.atomic == 2) return false;           // (a split product adds its bias in the reduce pass)
     if (!ta && (p.kseg % GB_BK) != 0) return false;     // a row image has no zero fill for a partial k-step
     return true;
 }
