@@ -36,19 +36,32 @@
 // take 3.8 us of matrix time.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
 
 #define LT_D 256
-#define LT_R 32
 #define LT_THREADS 512
 #define LT_KB 8                          // 32-wide contraction blocks of a 256-wide slice
-#define LT_IMG (LT_R * LT_D)             // elements of a [32 rows][256 k] operand image (16 KB)
+// A workgroup owns R = 16 RB rows, RB = 2 (the tall launches: one workgroup per CU at 8000 rows) or 1
+// (row counts that leave most CUs without a workgroup -- a decoder's 1056 rows: the launch takes as
+// long as ONE workgroup, and a workgroup with half the rows is done sooner).  RB is a template
+// parameter of everything below.
+#define LT_IMG(RB) (16 * (RB) * LT_D)    // elements of a [R rows][256 k] operand image (16 KB at RB = 2)
+// row blocks per workgroup for a launch of ``rows`` rows
+// (ATHENA_TAIL_SMALL_ROWS: the largest row count that gets the 16-row workgroups; default 2048 = half
+// the CUs busy with 32-row ones; 0 = never.  A forward and its backward launch must see the same value:
+// the slabs of the LayerNorm sums are one per workgroup.)
+static inline int lt_row_blocks(int rows) {
+    const char* v = getenv("ATHENA_TAIL_SMALL_ROWS");        // read on every call so that a test can switch it
+    return rows <= (v ? atoi(v) : 2048) ? 1 : 2;
+}
 
 // Operand image: eight [32 rows][32 k] blocks, 64-byte rows; the 16-byte chunk c of row r sits at
 // position c ^ 2*((r >> 2) & 1), which spreads the 16 rows of a fragment read over all banks.
+template <int RB>
 __device__ __forceinline__ int lt_img_off(int row, int k) {
     const int kb = k >> 5, c = (k >> 3) & 3;
-    return kb * (LT_R * 32) + (row * 4 + (c ^ (((row >> 2) & 1) << 1))) * 8 + (k & 7);
+    return kb * (16 * RB * 32) + (row * 4 + (c ^ (((row >> 2) & 1) << 1))) * 8 + (k & 7);
 }
 
 struct LtUnit {
@@ -79,26 +92,28 @@ __device__ __forceinline__ void lt_load_unit(LtUnit& u, const bf16_t* __restrict
 // k-block of the unit is requested again from ``next`` as soon as it has been multiplied (a
 // compile-time choice: behind a run-time branch the compiler has to place its waits for the path
 // that issued no loads, and every use of a fragment would then wait for the newest requests too).
-template <bool ROLL>
-__device__ __forceinline__ void lt_mul_unit(f32x4_t (&acc)[2][2], LtUnit& u, const bf16_t* img, int lane,
+template <bool ROLL, int RB>
+__device__ __forceinline__ void lt_mul_unit(f32x4_t (&acc)[RB][2], LtUnit& u, const bf16_t* img, int lane,
                                             const bf16_t* __restrict__ next, long next_ld) {
     const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
     for (int kb = 0; kb < LT_KB; ++kb) {
-        const bf16x8_t a0 = *(const bf16x8_t*)(img + lt_img_off(fr, kb * 32 + fk));
-        const bf16x8_t a1 = *(const bf16x8_t*)(img + lt_img_off(16 + fr, kb * 32 + fk));
+        bf16x8_t a[RB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a0, acc[0][j], 0, 0, 0);
-            acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a1, acc[1][j], 0, 0, 0);
-        }
+        for (int i = 0; i < RB; ++i) a[i] = *(const bf16x8_t*)(img + lt_img_off<RB>(16 * i + fr, kb * 32 + fk));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a[i], acc[i][j], 0, 0, 0);
         if (ROLL) lt_load_slot(u, kb, next, next_ld);
     }
 }
 
-__device__ __forceinline__ void lt_zero(f32x4_t (&acc)[2][2]) {
+template <int RB>
+__device__ __forceinline__ void lt_zero(f32x4_t (&acc)[RB][2]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 }
@@ -122,23 +137,26 @@ __device__ __forceinline__ float lt_round(float v) { return (float)(bf16_t)v; }
 
 // ---- row blocks between global memory and LDS images: 1024 pieces of 16 bytes, two per thread;
 // piece q = row q / 32, columns 8 (q % 32) .. + 7 of the block.
+template <int RB>
 struct LtTile {
-    bf16x8_t v[2];
+    bf16x8_t v[RB];
 };
 // rows row0 .. row0 + 31 (clamped to the last row), columns col0 .. col0 + 255 of src (row stride ld)
-__device__ __forceinline__ void lt_tile_load(LtTile& t, const bf16_t* __restrict__ src, long ld, int col0, int row0,
+template <int RB>
+__device__ __forceinline__ void lt_tile_load(LtTile<RB>& t, const bf16_t* __restrict__ src, long ld, int col0, int row0,
                                              int rows, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
         const int q = tid + u * LT_THREADS;
         t.v[u] = *(const bf16x8_t*)(src + (long)min(row0 + (q >> 5), rows - 1) * ld + col0 + (q & 31) * 8);
     }
 }
-__device__ __forceinline__ void lt_tile_to_img(bf16_t* img, const LtTile& t, int tid) {
+template <int RB>
+__device__ __forceinline__ void lt_tile_to_img(bf16_t* img, const LtTile<RB>& t, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
         const int q = tid + u * LT_THREADS;
-        *(bf16x8_t*)(img + lt_img_off(q >> 5, (q & 31) * 8)) = t.v[u];
+        *(bf16x8_t*)(img + lt_img_off<RB>(q >> 5, (q & 31) * 8)) = t.v[u];
     }
 }
 // A 16-byte store that writes through L2 without keeping the line there (sc1).  The row blocks a
@@ -155,10 +173,11 @@ __device__ __forceinline__ void lt_store16_through(bf16_t* base, long elem, bf16
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lt_u32x4, v), rsrc, (unsigned)(elem * 2), 0, 16 /* sc1 */);
 }
 
+template <int RB>
 __device__ __forceinline__ void lt_img_to_global(const bf16_t* img, bf16_t* __restrict__ dst, long ld, int col0,
                                                  int row0, int rows, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
         const int q = tid + u * LT_THREADS;
         const int r = q >> 5;
 #ifdef LT_X_NOSTORE
@@ -166,35 +185,38 @@ __device__ __forceinline__ void lt_img_to_global(const bf16_t* img, bf16_t* __re
 #else
         if (row0 + r < rows)
 #endif
-            lt_store16_through(dst, (long)(row0 + r) * ld + col0 + (q & 31) * 8, *(const bf16x8_t*)(img + lt_img_off(r, (q & 31) * 8)));
+            lt_store16_through(dst, (long)(row0 + r) * ld + col0 + (q & 31) * 8, *(const bf16x8_t*)(img + lt_img_off<RB>(r, (q & 31) * 8)));
     }
 }
 // the four values of an image a lane owns in accumulator layout (row r, columns n .. n + 3, n % 4 == 0)
+template <int RB>
 __device__ __forceinline__ bf16x4_t lt_img_get4(const bf16_t* img, int r, int n) {
-    return *(const bf16x4_t*)(img + lt_img_off(r, n));
+    return *(const bf16x4_t*)(img + lt_img_off<RB>(r, n));
 }
 
 // Two sums per row at once: the lane's own values are already added up in a[i], b[i]; the four lanes
 // that share a row inside a wave fold by shuffles, the eight waves through LDS (one barrier; the
 // caller separates two uses of ``red`` ([2][8][32] floats) by another barrier).
-__device__ __forceinline__ void lt_row_sums2(float (&a)[2], float (&b)[2], float* red, int wave, int lane) {
+template <int RB>
+__device__ __forceinline__ void lt_row_sums2(float (&a)[RB], float (&b)[RB], float* red, int wave, int lane) {
+    constexpr int R = 16 * RB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         a[i] = rows4_sum(a[i]);
         b[i] = rows4_sum(b[i]);
         if (lane < 16) {
-            red[wave * LT_R + 16 * i + lane] = a[i];
-            red[8 * LT_R + wave * LT_R + 16 * i + lane] = b[i];
+            red[wave * R + 16 * i + lane] = a[i];
+            red[8 * R + wave * R + 16 * i + lane] = b[i];
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         float t = 0.f, u = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-            t += red[w * LT_R + 16 * i + (lane & 15)];
-            u += red[8 * LT_R + w * LT_R + 16 * i + (lane & 15)];
+            t += red[w * R + 16 * i + (lane & 15)];
+            u += red[8 * R + w * R + 16 * i + (lane & 15)];
         }
         a[i] = t;
         b[i] = u;
@@ -206,15 +228,19 @@ __device__ __forceinline__ void lt_row_sums2(float (&a)[2], float (&b)[2], float
 // the LDS images zimg / yimg (the caller copies them out after its next barrier); mean / rstd go
 // straight to memory.  bias, gamma, beta: LDS.  red: two arrays of [8][32] floats.  One barrier inside,
 // between writing z and writing y.
-__device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res)[2][2][4], const float* bias,
+template <int RB>
+__device__ __forceinline__ void lt_add_ln(float (&v)[RB][2][4], const float (&res)[RB][2][4], const float* bias,
                                           const float* gamma, const float* beta, float eps, uint32_t thresh,
                                           float dscale, uint64_t key, int row0, int rows, int wave, int lane,
                                           float* __restrict__ mean, float* __restrict__ rstd, float* red, bf16_t* zimg,
                                           bf16_t* yimg) {
+    constexpr int R = 16 * RB;
     const int fr = lane & 15, fq = lane >> 4;
-    float s[2] = {0.f, 0.f};
+    float s[RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
         const int row = row0 + 16 * i + fr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -228,15 +254,15 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
                 v[i][j][r] = res[i][j][r] + (v[i][j][r] + bb[r]) * dm[r];
                 s[i] += v[i][j][r];
             }
-            lt_store4(zimg + lt_img_off(16 * i + fr, n), v[i][j]);
+            lt_store4(zimg + lt_img_off<RB>(16 * i + fr, n), v[i][j]);
         }
     }
     // statistics of the wave's own 32 columns (mean, sum of squared deviations from it) by shuffles,
     // then the eight pairs of a row are merged behind ONE barrier: the sum of squares about the row
     // mean is sum_w [M2_w + 32 (mean_w - mean)^2] -- no cancellation, no second pass over the block
-    float mu[2], q[2];
+    float mu[RB], q[RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         s[i] = rows4_sum(s[i]);
         const float mw = s[i] * (1.f / 32.f);
         float m2 = 0.f;
@@ -249,19 +275,19 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
             }
         m2 = rows4_sum(m2);
         if (lane < 16) {
-            red[wave * LT_R + 16 * i + lane] = mw;
-            red[8 * LT_R + wave * LT_R + 16 * i + lane] = m2;
+            red[wave * R + 16 * i + lane] = mw;
+            red[8 * R + wave * R + 16 * i + lane] = m2;
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         float mws[8], t = 0.f, u = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-            mws[w] = red[w * LT_R + 16 * i + fr];
+            mws[w] = red[w * R + 16 * i + fr];
             t += mws[w];
-            u += red[8 * LT_R + w * LT_R + 16 * i + fr];
+            u += red[8 * R + w * R + 16 * i + fr];
         }
         mu[i] = t * 0.125f;
 #pragma unroll
@@ -269,7 +295,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
         q[i] = u;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const int row = row0 + 16 * i + fr;
         const float rs = rsqrtf(q[i] * (1.f / LT_D) + eps);
         if (wave == 0 && fq == 0 && row < rows) {
@@ -284,7 +310,7 @@ __device__ __forceinline__ void lt_add_ln(float (&v)[2][2][4], const float (&res
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[i][j][r] = (v[i][j][r] - mu[i]) * rs * gg[r] + tt[r];
-            lt_store4(yimg + lt_img_off(16 * i + fr, n), v[i][j]);
+            lt_store4(yimg + lt_img_off<RB>(16 * i + fr, n), v[i][j]);
         }
     }
 }
@@ -337,17 +363,18 @@ struct LtFwd {
     bf16_t* on[3];
 };
 
-template <bool FFN, bool QKV = false>
+template <bool FFN, bool QKV, int RB>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd p) {
+    constexpr int R = 16 * RB;
     // extra products on the launch's output: three behind a feed-forward part (q, k, v of the next
     // layer's self-attention), one without it (the q of the cross-attention that follows a decoder's
     // self-attention sub-layer)
     // images: [0] ctx, then hidden slices (even)  [1] hidden slices (odd)  [2] y1
     //         [3], [4] staging: x, pre-activation slices (even / odd), z1, z2, y2
-    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 5 : 4][LT_IMG];
+    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 5 : 4][LT_IMG(RB)];
     __shared__ __attribute__((aligned(16))) float vecs[QKV ? 9 : 6][LT_D];   // bo gamma1 beta1 b2 gamma2 beta2 (bq bk bv)
     __shared__ __attribute__((aligned(16))) float b1s[FFN ? LT_MAX_DFF : 4];
-    __shared__ float red[2 * 8 * LT_R];
+    __shared__ float red[2 * 8 * R];
     bf16_t* const img_a = imgs[0];
     bf16_t* const img_h = imgs[1];
     bf16_t* const img_y = imgs[2];
@@ -356,15 +383,15 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int row0 = blockIdx.x * LT_R;
+    const int row0 = blockIdx.x * R;
     const int nslice = FFN ? p.dff / LT_D : 0;
     const int n0 = 32 * wave;
 
     LT_STAMP(0);
     // ---- everything small first: these are the last loads that are waited for as a group
-    LtTile tc, tx;
-    lt_tile_load(tc, p.ctx, LT_D, 0, row0, p.rows, tid);
-    lt_tile_load(tx, p.x, LT_D, 0, row0, p.rows, tid);
+    LtTile<RB> tc, tx;
+    lt_tile_load<RB>(tc, p.ctx, LT_D, 0, row0, p.rows, tid);
+    lt_tile_load<RB>(tx, p.x, LT_D, 0, row0, p.rows, tid);
     const bool hi = tid >= LT_D;
     const int ve = tid & (LT_D - 1);
     float vv[3], bv[LT_MAX_DFF / LT_THREADS];
@@ -388,8 +415,8 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
     if (FFN) lt_load_unit(ub, lt_unit_ptr(p.w1, LT_D, n0, 0, lane), LT_D);
     __builtin_amdgcn_sched_barrier(0);
-    lt_tile_to_img(img_a, tc, tid);
-    lt_tile_to_img(st0, tx, tid);
+    lt_tile_to_img<RB>(img_a, tc, tid);
+    lt_tile_to_img<RB>(st0, tx, tid);
     vecs[hi][ve] = vv[0];
     vecs[2 + hi][ve] = vv[1];
     vecs[4 + hi][ve] = vv[2];
@@ -406,26 +433,26 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     __syncthreads();
     LT_STAMP(1);
 
-    float res[2][2][4];                                         // the residual input, in accumulator layout
+    float res[RB][2][4];                                         // the residual input, in accumulator layout
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const bf16x4_t t = lt_img_get4(st0, 16 * i + fr, n0 + 16 * j + 4 * fq);
+            const bf16x4_t t = lt_img_get4<RB>(st0, 16 * i + fr, n0 + 16 * j + 4 * fq);
 #pragma unroll
             for (int r = 0; r < 4; ++r) res[i][j][r] = (float)t[r];
         }
-    f32x4_t acc[2][2];
-    float v[2][2][4];
-    lt_zero(acc);
+    f32x4_t acc[RB][2];
+    float v[RB][2][4];
+    lt_zero<RB>(acc);
     // ctx Wo; the projection's registers are refilled with slice 0 of the second Dense (without a
     // feed-forward part: with the unit of the one extra product, if there is one)
-    lt_mul_unit<FFN || QKV>(acc, ua, img_a, lane,
+    lt_mul_unit<FFN || QKV, RB>(acc, ua, img_a, lane,
                             FFN ? lt_unit_ptr(p.w2, p.dff, n0, 0, lane) : lt_unit_ptr(p.wn[0], LT_D, n0, 0, lane),
                             FFN ? (long)p.dff : (long)LT_D);
     LT_STAMP(2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -433,49 +460,49 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     uint64_t key = 0;
     if (p.thresh) key = rng_key(p.rng_state, p.site_res1);
     // z1 -> st1 (st0 may still be read for x by slower waves), y1 -> img_y
-    lt_add_ln(v, res, vecs[0], vecs[1], vecs[2], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean1,
+    lt_add_ln<RB>(v, res, vecs[0], vecs[1], vecs[2], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean1,
               p.rstd1, red, FFN ? st1 : st0, img_y);
     __syncthreads();                                         // z1 and y1 images complete; img_a free again
     LT_STAMP(3);
-    lt_img_to_global(FFN ? st1 : st0, p.z1, LT_D, 0, row0, p.rows, tid);
-    lt_img_to_global(img_y, p.y1, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(FFN ? st1 : st0, p.z1, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(img_y, p.y1, LT_D, 0, row0, p.rows, tid);
     LT_STAMP(4);
     if constexpr (!FFN && QKV) {
         // y1 Wn + bn into the image the attention context came in (read for the last time before the
         // barrier above)
-        lt_zero(acc);
-        lt_mul_unit<false>(acc, ua, img_y, lane, nullptr, 0);
+        lt_zero<RB>(acc);
+        lt_mul_unit<false, RB>(acc, ua, img_y, lane, nullptr, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = n0 + 16 * j + 4 * fq;
                 const float4 b4 = *(const float4*)(&vecs[6][n]);
                 const float o[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-                lt_store4(img_a + lt_img_off(16 * i + fr, n), o);
+                lt_store4(img_a + lt_img_off<RB>(16 * i + fr, n), o);
             }
         __syncthreads();
-        lt_img_to_global(img_a, p.on[0], LT_D, 0, row0, p.rows, tid);
+        lt_img_to_global<RB>(img_a, p.on[0], LT_D, 0, row0, p.rows, tid);
     }
     if (!FFN) return;
 
     // v now holds y1 (the residual of the second half)
-    f32x4_t facc[2][2];
-    lt_zero(facc);
+    f32x4_t facc[RB][2];
+    lt_zero<RB>(facc);
     uint64_t hkey = 0;
     if (p.thresh) hkey = rng_key(p.rng_state, p.site_ffn);
     auto slice = [&](int c, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
         bf16_t* himg = (c & 1) ? img_h : img_a;
         bf16_t* pimg = (c & 1) ? st1 : st0;
-        lt_zero(acc);
+        lt_zero<RB>(acc);
         // (the last slice requests the next layer's q and k units in place of a next slice's)
-        lt_mul_unit<MORE || QKV>(acc, ub, img_y, lane,
+        lt_mul_unit<MORE || QKV, RB>(acc, ub, img_y, lane,
                                  MORE ? lt_unit_ptr(p.w1, LT_D, (c + 1) * LT_D + n0, 0, lane)
                                       : lt_unit_ptr(p.wn[0], LT_D, n0, 0, lane), LT_D);          // y1 W1[slice c]
         LT_STAMP(8 + 5 * c);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             const int row = row0 + 16 * i + fr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -490,17 +517,17 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
                     pre[r] = acc[i][j][r] + bb[r];
                     hv[r] = gelu_tanh_f(pre[r]) * dm[r];
                 }
-                lt_store4(pimg + lt_img_off(16 * i + fr, nl), pre);
-                lt_store4(himg + lt_img_off(16 * i + fr, nl), hv);
+                lt_store4(pimg + lt_img_off<RB>(16 * i + fr, nl), pre);
+                lt_store4(himg + lt_img_off<RB>(16 * i + fr, nl), hv);
             }
         }
         LT_STAMP(9 + 5 * c);
         __syncthreads();                                     // slice c of the hidden layer is in LDS
         LT_STAMP(10 + 5 * c);
-        lt_img_to_global(pimg, p.hpre, p.dff, c * LT_D, row0, p.rows, tid);
-        lt_img_to_global(himg, p.h, p.dff, c * LT_D, row0, p.rows, tid);
+        lt_img_to_global<RB>(pimg, p.hpre, p.dff, c * LT_D, row0, p.rows, tid);
+        lt_img_to_global<RB>(himg, p.h, p.dff, c * LT_D, row0, p.rows, tid);
         LT_STAMP(11 + 5 * c);
-        lt_mul_unit<MORE || QKV>(facc, ua, himg, lane,
+        lt_mul_unit<MORE || QKV, RB>(facc, ua, himg, lane,
                                  MORE ? lt_unit_ptr(p.w2, p.dff, n0, (c + 1) * LT_D, lane)
                                       : lt_unit_ptr(p.wn[1], LT_D, n0, 0, lane),
                                  MORE ? (long)p.dff : (long)LT_D);                              // += h[slice c] W2[slice c, :]
@@ -508,9 +535,9 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     };
     for (int c = 0; c + 1 < nslice; ++c) slice(c, std::true_type{});
     slice(nslice - 1, std::false_type{});
-    float f[2][2][4];
+    float f[RB][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -519,12 +546,12 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     // the images of the parity the last slice did not use are free: no wave reads them any more
     bf16_t* zimg = (nslice & 1) ? st1 : st0;
     bf16_t* yimg = (nslice & 1) ? img_h : img_a;
-    lt_add_ln(f, v, vecs[3], vecs[4], vecs[5], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean2,
+    lt_add_ln<RB>(f, v, vecs[3], vecs[4], vecs[5], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean2,
               p.rstd2, red, zimg, yimg);
     LT_STAMP(5);
     __syncthreads();
-    lt_img_to_global(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
-    lt_img_to_global(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
     LT_STAMP(6);
     if constexpr (QKV && FFN) {
         // ub holds the q unit, ua the k unit; the v unit takes ub's place as that is multiplied.  The
@@ -532,16 +559,16 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         // other parity and y1's) and leave together behind one barrier.
         bf16_t* const oimg[3] = {(nslice & 1) ? img_a : img_h, (nslice & 1) ? st0 : st1, img_y};
         auto project = [&](int m, LtUnit& u, auto roll_tag) {
-            lt_zero(acc);
-            lt_mul_unit<decltype(roll_tag)::value>(acc, u, yimg, lane, lt_unit_ptr(p.wn[2], LT_D, n0, 0, lane), LT_D);
+            lt_zero<RB>(acc);
+            lt_mul_unit<decltype(roll_tag)::value, RB>(acc, u, yimg, lane, lt_unit_ptr(p.wn[2], LT_D, n0, 0, lane), LT_D);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + 16 * j + 4 * fq;
                     const float4 b4 = *(const float4*)(&vecs[6 + m][n]);
                     const float o[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-                    lt_store4(oimg[m] + lt_img_off(16 * i + fr, n), o);
+                    lt_store4(oimg[m] + lt_img_off<RB>(16 * i + fr, n), o);
                 }
         };
         project(0, ub, std::true_type{});
@@ -553,7 +580,7 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
         __syncthreads();
         LT_STAMP(31);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) lt_img_to_global(oimg[m], p.on[m], LT_D, 0, row0, p.rows, tid);
+        for (int m = 0; m < 3; ++m) lt_img_to_global<RB>(oimg[m], p.on[m], LT_D, 0, row0, p.rows, tid);
         LT_STAMP(32);
     }
 }
@@ -563,18 +590,21 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
 // sums for dgamma / dbeta into ``slab`` ([2][256], one slab per workgroup: every column belongs to
 // one wave, so the slab is written without atomics).  dy comes in as g, dz leaves in g; zv holds
 // the LayerNorm input, mean / rstd (indexed by the row inside the block) and gamma live in LDS.
-__device__ __forceinline__ void lt_ln_bwd(float (&g)[2][2][4], const bf16x4_t (&zv)[2][2], const float* mean,
+template <int RB>
+__device__ __forceinline__ void lt_ln_bwd(float (&g)[RB][2][4], const bf16x4_t (&zv)[RB][2], const float* mean,
                                           const float* rstd, const float* gamma, int row0, int rows, int wave, int lane,
                                           float* red, float* __restrict__ slab) {
     const int fr = lane & 15, fq = lane >> 4;
-    float xh[2][2][4], rs[2], c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+    float xh[RB][2][4], rs[RB], c1[RB], c2[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) { c1[i] = 0.f; c2[i] = 0.f; }
     float pg[2][4], pb[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pg[j][r] = 0.f; pb[j][r] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const bool live = row0 + 16 * i + fr < rows;
         const float mu = mean[16 * i + fr];
         rs[i] = rstd[16 * i + fr];
@@ -595,7 +625,7 @@ __device__ __forceinline__ void lt_ln_bwd(float (&g)[2][2][4], const bf16x4_t (&
             }
         }
     }
-    // column sums over the 32 rows: lanes with equal (lane >> 4) hold the same columns
+    // column sums over the workgroup's rows: lanes with equal (lane >> 4) hold the same columns
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -609,9 +639,9 @@ __device__ __forceinline__ void lt_ln_bwd(float (&g)[2][2][4], const bf16x4_t (&
                 slab[LT_D + n] = b;
             }
         }
-    lt_row_sums2(c1, c2, red, wave, lane);
+    lt_row_sums2<RB>(c1, c2, red, wave, lane);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const float m1 = c1[i] * (1.f / LT_D), m2 = c2[i] * (1.f / LT_D);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -654,17 +684,18 @@ struct LtBwd {
     const bf16_t* aw[3];
 };
 
-template <bool FFN, bool ADD = false>
+template <bool FFN, bool ADD, int RB>
 __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd p) {
+    constexpr int R = 16 * RB;
     // products added to dy: dq | dk | dv of a self-attention behind a layer with a feed-forward part,
     // the dq of the cross-attention behind a decoder's self-attention sub-layer
     constexpr int NA = FFN ? 3 : 1;
     // images: [0] df, later da  [1] z1  [2], [3] dh slices (even / odd); before the slices dy and z2,
     //         after them dx and dctx  [4], [5] pre-activation slices (even / odd)
-    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 6 : 4][LT_IMG];
+    __shared__ __attribute__((aligned(16))) bf16_t imgs[FFN ? 6 : 4][LT_IMG(RB)];
     __shared__ __attribute__((aligned(16))) float gam[2][LT_D];          // gamma2, gamma1
-    __shared__ float stat[4][LT_R];                                      // mean2 rstd2 mean1 rstd1
-    __shared__ float red[2 * 8 * LT_R];
+    __shared__ float stat[4][R];                                      // mean2 rstd2 mean1 rstd1
+    __shared__ float red[2 * 8 * R];
     __shared__ f32x4_t park[FFN ? 4 : 1][LT_THREADS];                    // dz2 of each thread while the slices run
     bf16_t* const img_a = imgs[0];
     bf16_t* const img_z1 = imgs[1];
@@ -673,30 +704,30 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int row0 = blockIdx.x * LT_R;
+    const int row0 = blockIdx.x * R;
     const int nslice = FFN ? p.dff / LT_D : 0;
     const int n0 = 32 * wave;
 
     // ---- everything small first (see the forward kernel)
-    LtTile tz1, tdy, tz2, thp;
-    lt_tile_load(tz1, p.z1, LT_D, 0, row0, p.rows, tid);
-    lt_tile_load(tdy, p.dy, LT_D, 0, row0, p.rows, tid);
+    LtTile<RB> tz1, tdy, tz2, thp;
+    lt_tile_load<RB>(tz1, p.z1, LT_D, 0, row0, p.rows, tid);
+    lt_tile_load<RB>(tdy, p.dy, LT_D, 0, row0, p.rows, tid);
     if (FFN) {
-        lt_tile_load(tz2, p.z2, LT_D, 0, row0, p.rows, tid);
-        lt_tile_load(thp, p.hpre, p.dff, 0, row0, p.rows, tid);
+        lt_tile_load<RB>(tz2, p.z2, LT_D, 0, row0, p.rows, tid);
+        lt_tile_load<RB>(thp, p.hpre, p.dff, 0, row0, p.rows, tid);
     }
-    LtTile tadd[NA];
+    LtTile<RB> tadd[NA];
     if constexpr (ADD) {
 #pragma unroll
-        for (int m = 0; m < NA; ++m) lt_tile_load(tadd[m], p.add, NA * LT_D, m * LT_D, row0, p.rows, tid);
+        for (int m = 0; m < NA; ++m) lt_tile_load<RB>(tadd[m], p.add, NA * LT_D, m * LT_D, row0, p.rows, tid);
     }
     const bool hi = tid >= LT_D;
     const int ve = tid & (LT_D - 1);
     float gv = 0.f, sv = 0.f;
     if (hi || FFN) gv = (hi ? p.gamma1 : p.gamma2)[ve];
-    if (tid < 4 * LT_R) {
-        const int which = tid >> 5;
-        const int row = min(row0 + (tid & 31), p.rows - 1);
+    if (tid < 4 * R) {
+        const int which = tid / R;
+        const int row = min(row0 + (tid % R), p.rows - 1);
         if (which >= 2 || FFN) sv = (which == 0 ? p.mean2 : which == 1 ? p.rstd2 : which == 2 ? p.mean1 : p.rstd1)[row];
     }
     // ---- weights
@@ -705,49 +736,49 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     else lt_load_unit(ua, lt_unit_ptr(p.wo, LT_D, n0, 0, lane), LT_D);
     if constexpr (ADD) lt_load_unit(ub, lt_unit_ptr(p.aw[0], LT_D, n0, 0, lane), LT_D);
     __builtin_amdgcn_sched_barrier(0);
-    lt_tile_to_img(img_z1, tz1, tid);
-    lt_tile_to_img(img_h0, tdy, tid);
+    lt_tile_to_img<RB>(img_z1, tz1, tid);
+    lt_tile_to_img<RB>(img_h0, tdy, tid);
     // dq, dk, dv rows: the two images nothing uses yet and the parking space of dz2 (written only
     // behind the barrier inside the first LayerNorm'); without the feed-forward part the one image
     // that is not used before the end
     bf16_t* const img_add[3] = {imgs[FFN ? 0 : 3], imgs[FFN ? 5 : 0], reinterpret_cast<bf16_t*>(&park[0][0])};
     if constexpr (ADD) {
 #pragma unroll
-        for (int m = 0; m < NA; ++m) lt_tile_to_img(img_add[m], tadd[m], tid);
+        for (int m = 0; m < NA; ++m) lt_tile_to_img<RB>(img_add[m], tadd[m], tid);
     }
     if (FFN) {
-        lt_tile_to_img(img_h1, tz2, tid);
-        lt_tile_to_img(imgs[4], thp, tid);
-        if (nslice > 1) lt_tile_load(thp, p.hpre, p.dff, LT_D, row0, p.rows, tid);    // slice 1, kept in registers
+        lt_tile_to_img<RB>(img_h1, tz2, tid);
+        lt_tile_to_img<RB>(imgs[4], thp, tid);
+        if (nslice > 1) lt_tile_load<RB>(thp, p.hpre, p.dff, LT_D, row0, p.rows, tid);    // slice 1, kept in registers
     }
     gam[hi][ve] = gv;
-    if (tid < 4 * LT_R) stat[tid >> 5][tid & 31] = sv;
+    if (tid < 4 * R) stat[tid / R][tid % R] = sv;
     __syncthreads();                                         // staged blocks and vectors visible
 
-    float g[2][2][4];
-    bf16x4_t zv[2][2];
+    float g[RB][2][4];
+    bf16x4_t zv[RB][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + 16 * j + 4 * fq;
-            const bf16x4_t t = lt_img_get4(img_h0, 16 * i + fr, n);
+            const bf16x4_t t = lt_img_get4<RB>(img_h0, 16 * i + fr, n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) g[i][j][r] = (float)t[r];
-            if (FFN) zv[i][j] = lt_img_get4(img_h1, 16 * i + fr, n);
+            if (FFN) zv[i][j] = lt_img_get4<RB>(img_h1, 16 * i + fr, n);
         }
     if constexpr (ADD) {
-        f32x4_t aacc[2][2];
-        lt_zero(aacc);
+        f32x4_t aacc[RB][2];
+        lt_zero<RB>(aacc);
         if constexpr (NA == 3) {
-            lt_mul_unit<true>(aacc, ub, img_add[0], lane, lt_unit_ptr(p.aw[1], LT_D, n0, 0, lane), LT_D);
-            lt_mul_unit<true>(aacc, ub, img_add[1], lane, lt_unit_ptr(p.aw[2], LT_D, n0, 0, lane), LT_D);
-            lt_mul_unit<false>(aacc, ub, img_add[2], lane, nullptr, 0);
+            lt_mul_unit<true, RB>(aacc, ub, img_add[0], lane, lt_unit_ptr(p.aw[1], LT_D, n0, 0, lane), LT_D);
+            lt_mul_unit<true, RB>(aacc, ub, img_add[1], lane, lt_unit_ptr(p.aw[2], LT_D, n0, 0, lane), LT_D);
+            lt_mul_unit<false, RB>(aacc, ub, img_add[2], lane, nullptr, 0);
         } else {
-            lt_mul_unit<false>(aacc, ub, img_add[0], lane, nullptr, 0);
+            lt_mul_unit<false, RB>(aacc, ub, img_add[0], lane, nullptr, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -755,13 +786,13 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     }
     uint64_t key = 0;
     if (FFN) {
-        lt_ln_bwd(g, zv, stat[0], stat[1], gam[0], row0, p.rows, wave, lane, red,
+        lt_ln_bwd<RB>(g, zv, stat[0], stat[1], gam[0], row0, p.rows, wave, lane, red,
                   p.slab2 + (long)blockIdx.x * 2 * LT_D);
         // g = dz2: the gradient of y1 through the residual, and (masked) the gradient of f
         lt_load_unit(ub, lt_unit_ptr(p.w1, p.dff, n0, 0, lane), p.dff);      // rows n0.. of W1, k over slice 0
         if (p.thresh) key = rng_key(p.rng_state, p.site_res2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             const int row = row0 + 16 * i + fr;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -770,14 +801,14 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
                 if (p.thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, p.thresh, p.dscale, dm);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dfv[r] = g[i][j][r] * dm[r];
-                lt_store4(img_a + lt_img_off(16 * i + fr, n), dfv);
+                lt_store4(img_a + lt_img_off<RB>(16 * i + fr, n), dfv);
                 park[FFN ? 2 * i + j : 0][tid] = (f32x4_t){g[i][j][0], g[i][j][1], g[i][j][2], g[i][j][3]};
             }
         }
         __syncthreads();                                     // df image complete
-        lt_img_to_global(img_a, p.df, LT_D, 0, row0, p.rows, tid);
-        f32x4_t acc[2][2], dacc[2][2];
-        lt_zero(dacc);
+        lt_img_to_global<RB>(img_a, p.df, LT_D, 0, row0, p.rows, tid);
+        f32x4_t acc[RB][2], dacc[RB][2];
+        lt_zero<RB>(dacc);
         uint64_t hkey = 0;
         if (p.thresh) hkey = rng_key(p.rng_state, p.site_ffn);
         // Pre-activations travel two slices ahead: slice c + 2 is requested (into registers) while
@@ -787,38 +818,38 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
             constexpr bool MORE = decltype(more_tag)::value;
             bf16_t* himg = (c & 1) ? img_h1 : img_h0;
             const bf16_t* pimg = imgs[4 + (c & 1)];
-            lt_zero(acc);
+            lt_zero<RB>(acc);
             // df W2[slice c]^T; the registers take slice c + 1, or the projection after the last slice
-            lt_mul_unit<true>(acc, ua, img_a, lane,
+            lt_mul_unit<true, RB>(acc, ua, img_a, lane,
                               MORE ? lt_unit_ptr(p.w2, LT_D, (c + 1) * LT_D + n0, 0, lane) : lt_unit_ptr(p.wo, LT_D, n0, 0, lane),
                               LT_D);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 const int row = row0 + 16 * i + fr;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int nl = n0 + 16 * j + 4 * fq;
                     const int n = c * LT_D + nl;
-                    const bf16x4_t hp = lt_img_get4(pimg, 16 * i + fr, nl);
+                    const bf16x4_t hp = lt_img_get4<RB>(pimg, 16 * i + fr, nl);
                     float dv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
                     if (p.thresh) lt_dropout4(hkey, (uint64_t)row * p.dff + n, p.thresh, p.dscale, dm);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dv[r] = acc[i][j][r] * dgelu_tanh_f((float)hp[r]) * dm[r];
-                    lt_store4(himg + lt_img_off(16 * i + fr, nl), dv);
+                    lt_store4(himg + lt_img_off<RB>(16 * i + fr, nl), dv);
                 }
             }
             if (MORE) {
-                lt_tile_to_img(imgs[5 - (c & 1)], thp, tid);
-                if (c + 2 < nslice) lt_tile_load(thp, p.hpre, p.dff, (c + 2) * LT_D, row0, p.rows, tid);
+                lt_tile_to_img<RB>(imgs[5 - (c & 1)], thp, tid);
+                if (c + 2 < nslice) lt_tile_load<RB>(thp, p.hpre, p.dff, (c + 2) * LT_D, row0, p.rows, tid);
             }
             __syncthreads();                                 // slice c of dh is in LDS
-            lt_img_to_global(himg, p.dh, p.dff, c * LT_D, row0, p.rows, tid);
-            lt_mul_unit<MORE>(dacc, ub, himg, lane, lt_unit_ptr(p.w1, p.dff, n0, (c + 1) * LT_D, lane), p.dff);  // += dh[slice c] W1[:, slice c]^T
+            lt_img_to_global<RB>(himg, p.dh, p.dff, c * LT_D, row0, p.rows, tid);
+            lt_mul_unit<MORE, RB>(dacc, ub, himg, lane, lt_unit_ptr(p.w1, p.dff, n0, (c + 1) * LT_D, lane), p.dff);  // += dh[slice c] W1[:, slice c]^T
         };
         for (int c = 0; c + 1 < nslice; ++c) slice(c, std::true_type{});
         slice(nslice - 1, std::false_type{});
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4_t t = park[FFN ? 2 * i + j : 0][tid];
@@ -828,14 +859,14 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
     }
     // g = gradient of y1
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) zv[i][j] = lt_img_get4(img_z1, 16 * i + fr, n0 + 16 * j + 4 * fq);
-    lt_ln_bwd(g, zv, stat[2], stat[3], gam[1], row0, p.rows, wave, lane, red, p.slab1 + (long)blockIdx.x * 2 * LT_D);
+        for (int j = 0; j < 2; ++j) zv[i][j] = lt_img_get4<RB>(img_z1, 16 * i + fr, n0 + 16 * j + 4 * fq);
+    lt_ln_bwd<RB>(g, zv, stat[2], stat[3], gam[1], row0, p.rows, wave, lane, red, p.slab1 + (long)blockIdx.x * 2 * LT_D);
     // (a barrier passed: nobody reads the dh images or, without the feed-forward part, dy any more)
     if (p.thresh) key = rng_key(p.rng_state, p.site_res1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const int row = row0 + 16 * i + fr;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -844,31 +875,34 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_bwd_kernel(const LtBwd 
             if (p.thresh) lt_dropout4(key, (uint64_t)row * LT_D + n, p.thresh, p.dscale, dm);
 #pragma unroll
             for (int r = 0; r < 4; ++r) dav[r] = g[i][j][r] * dm[r];
-            lt_store4(img_h0 + lt_img_off(16 * i + fr, n), g[i][j]);
-            lt_store4(img_a + lt_img_off(16 * i + fr, n), dav);
+            lt_store4(img_h0 + lt_img_off<RB>(16 * i + fr, n), g[i][j]);
+            lt_store4(img_a + lt_img_off<RB>(16 * i + fr, n), dav);
         }
     }
     __syncthreads();                                         // da and dx images complete
-    lt_img_to_global(img_h0, p.dx, LT_D, 0, row0, p.rows, tid);
-    lt_img_to_global(img_a, p.da, LT_D, 0, row0, p.rows, tid);
-    f32x4_t cacc[2][2];
-    lt_zero(cacc);
-    lt_mul_unit<false>(cacc, ua, img_a, lane, nullptr, 0);   // da Wo^T
+    lt_img_to_global<RB>(img_h0, p.dx, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(img_a, p.da, LT_D, 0, row0, p.rows, tid);
+    f32x4_t cacc[RB][2];
+    lt_zero<RB>(cacc);
+    lt_mul_unit<false, RB>(cacc, ua, img_a, lane, nullptr, 0);   // da Wo^T
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float o[4] = {cacc[i][j][0], cacc[i][j][1], cacc[i][j][2], cacc[i][j][3]};
-            lt_store4(img_h1 + lt_img_off(16 * i + fr, n0 + 16 * j + 4 * fq), o);
+            lt_store4(img_h1 + lt_img_off<RB>(16 * i + fr, n0 + 16 * j + 4 * fq), o);
         }
     __syncthreads();
-    lt_img_to_global(img_h1, p.dctx, LT_D, 0, row0, p.rows, tid);
+    lt_img_to_global<RB>(img_h1, p.dctx, LT_D, 0, row0, p.rows, tid);
 }
 
 // ------------------------------------------------------------------------------------- C ABI
 static bool lt_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-extern "C" int athena_layer_tail_workgroups(int rows) { return rows > 0 ? (rows + LT_R - 1) / LT_R : 0; }
+extern "C" int athena_layer_tail_workgroups(int rows) {
+    const int r = 16 * lt_row_blocks(rows);
+    return rows > 0 ? (rows + r - 1) / r : 0;
+}
 
 extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena_stream_t stream) {
     ATHENA_REQUIRE(d, ATHENA_E_SHAPE, "athena_layer_tail_fwd: null descriptor");
@@ -914,18 +948,19 @@ extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena
         p.bn[m] = d->next_b[m];
         p.on[m] = (bf16_t*)d->next_out[m];
     }
-    if (qkv && d->dff > 0)
-        ATHENA_LAUNCH((layer_tail_fwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
-                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
-    else if (qkv)
-        ATHENA_LAUNCH((layer_tail_fwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
-                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
-    else if (d->dff > 0)
-        ATHENA_LAUNCH(layer_tail_fwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
-                           (hipStream_t)stream, p);
-    else
-        ATHENA_LAUNCH(layer_tail_fwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
-                           (hipStream_t)stream, p);
+    const dim3 grid(athena_layer_tail_workgroups(d->rows));
+#define LT_FWD(F, Q)                                                                                              \
+    do {                                                                                                          \
+        if (lt_row_blocks(d->rows) == 1)                                                                          \
+            ATHENA_LAUNCH((layer_tail_fwd_kernel<F, Q, 1>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p); \
+        else                                                                                                      \
+            ATHENA_LAUNCH((layer_tail_fwd_kernel<F, Q, 2>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p); \
+    } while (0)
+    if (qkv && d->dff > 0) LT_FWD(true, true);
+    else if (qkv) LT_FWD(false, true);
+    else if (d->dff > 0) LT_FWD(true, false);
+    else LT_FWD(false, false);
+#undef LT_FWD
     ATHENA_CHECK_LAUNCH("athena_layer_tail_fwd");
     return ATHENA_OK;
 }
@@ -967,18 +1002,19 @@ extern "C" int athena_layer_tail_bwd(const athena_layer_tail_bwd_desc* d, athena
                                    "feed-forward part, one without) and 16-byte aligned operands");
     p.add = (const bf16_t*)d->add_dqkv;
     for (int m = 0; m < 3; ++m) p.aw[m] = (const bf16_t*)d->add_w[m];
-    if (add && d->dff > 0)
-        ATHENA_LAUNCH((layer_tail_bwd_kernel<true, true>), dim3(athena_layer_tail_workgroups(d->rows)),
-                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
-    else if (add)
-        ATHENA_LAUNCH((layer_tail_bwd_kernel<false, true>), dim3(athena_layer_tail_workgroups(d->rows)),
-                           dim3(LT_THREADS), 0, (hipStream_t)stream, p);
-    else if (d->dff > 0)
-        ATHENA_LAUNCH(layer_tail_bwd_kernel<true>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
-                           (hipStream_t)stream, p);
-    else
-        ATHENA_LAUNCH(layer_tail_bwd_kernel<false>, dim3(athena_layer_tail_workgroups(d->rows)), dim3(LT_THREADS), 0,
-                           (hipStream_t)stream, p);
+    const dim3 grid(athena_layer_tail_workgroups(d->rows));
+#define LT_BWD(F, A)                                                                                              \
+    do {                                                                                                          \
+        if (lt_row_blocks(d->rows) == 1)                                                                          \
+            ATHENA_LAUNCH((layer_tail_bwd_kernel<F, A, 1>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p); \
+        else                                                                                                      \
+            ATHENA_LAUNCH((layer_tail_bwd_kernel<F, A, 2>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p); \
+    } while (0)
+    if (add && d->dff > 0) LT_BWD(true, true);
+    else if (add) LT_BWD(false, true);
+    else if (d->dff > 0) LT_BWD(true, false);
+    else LT_BWD(false, false);
+#undef LT_BWD
     ATHENA_CHECK_LAUNCH("athena_layer_tail_bwd");
     return ATHENA_OK;
 }

@@ -1055,8 +1055,16 @@ def _encoder_layer_run(monkeypatch, fused, dff, B, T, rate, seed=5):
     return y.detach().float(), x.grad.detach().float(), grads
 
 
+@pytest.fixture(params=["2048", "0"], ids=["rows16", "rows32"])
+def tail_rows(request, monkeypatch):
+    """Both builds of the one-launch layer tails: workgroups of 16 rows (what a launch with few rows
+    gets) and of 32 rows (the tall launches), whatever the row count of the test."""
+    monkeypatch.setenv("ATHENA_TAIL_SMALL_ROWS", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("dff,B,T,rate", [(1024, 4, 64, 0.0), (512, 3, 50, 0.1), (256, 1, 7, 0.1)])
-def test_layer_tail_matches_separate_kernels(ops, monkeypatch, dff, B, T, rate):
+def test_layer_tail_matches_separate_kernels(ops, monkeypatch, tail_rows, dff, B, T, rate):
     """The one-launch layer tail (output projection, LayerNorms, feed-forward block; reference
     athena/layers/transformer.py:296-310) against the same layer run as separate Dense / LayerNorm
     launches: same dropout decisions, so the two differ by bf16 rounding of intermediates only (the
@@ -1075,7 +1083,7 @@ def test_layer_tail_matches_separate_kernels(ops, monkeypatch, dff, B, T, rate):
 
 
 @pytest.mark.parametrize("dff,B,T", [(1024, 4, 64), (512, 2, 45)])
-def test_layer_tail_against_the_oracle_layer(ops, monkeypatch, dff, B, T):
+def test_layer_tail_against_the_oracle_layer(ops, monkeypatch, tail_rows, dff, B, T):
     """The bf16 encoder layer with the one-launch tails (the benchmarked path) against
     ``oracle.model.encoder_layer`` (TransformerEncoderLayer.call, reference
     athena/layers/transformer.py:296-310) in fp64 on the values the GPU sees -- input and weight
@@ -1135,7 +1143,7 @@ def test_layer_tail_against_the_oracle_layer(ops, monkeypatch, dff, B, T):
     assert checked >= 15
 
 
-def test_layer_tail_repeats_bit_for_bit(ops, monkeypatch):
+def test_layer_tail_repeats_bit_for_bit(ops, monkeypatch, tail_rows):
     """Twelve repetitions of the same layer on the same inputs give the same bits in every output and
     gradient: nothing in the tails (or in the weight-gradient table behind them) depends on timing.
     (Write-through stores issued as inline assembly once stored garbage here now and then: the wait
@@ -1182,7 +1190,7 @@ def _encoder_stack_run(monkeypatch, fold, dff, B, T, rate, nlayers=3, seed=9):
 
 
 @pytest.mark.parametrize("dff,B,T,rate", [(1024, 4, 64, 0.0), (512, 3, 50, 0.1), (768, 1, 7, 0.1)])
-def test_layer_tail_runs_the_next_layers_projections(ops, monkeypatch, dff, B, T, rate):
+def test_layer_tail_runs_the_next_layers_projections(ops, monkeypatch, tail_rows, dff, B, T, rate):
     """A stack whose layer tails also run the q / k / v projections of the layer behind them
     (MultiHeadAttention.call, reference athena/layers/attention.py:150-153) against the same stack
     with the projections as a launch of their own: the same products on the same bf16 inputs, summed
@@ -1262,7 +1270,7 @@ def _decoder_stack_run(monkeypatch, tails, fold, dff, B, L, T, rate, nlayers=3, 
 
 
 @pytest.mark.parametrize("dff,B,L,T,rate", [(1024, 4, 33, 64, 0.0), (512, 3, 20, 50, 0.1)])
-def test_decoder_tails_and_handed_over_products(ops, monkeypatch, dff, B, L, T, rate):
+def test_decoder_tails_and_handed_over_products(ops, monkeypatch, tail_rows, dff, B, L, T, rate):
     """A decoder stack three ways: separate Dense / LayerNorm launches; one-launch tails; tails that
     also run the self-attention projections of the layer behind them and, backwards, add the input
     gradient of those projections (reference athena/layers/transformer.py:374-388).  Same dropout
