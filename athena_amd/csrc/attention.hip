@@ -281,6 +281,16 @@ static bool mha_mfma_ok(int dtype, int dk, std::initializer_list<int> lds, std::
 }
 
 // the causal test of the scores is compiled in only where it is asked for
+static bool mha_plain_order() {
+    static const bool v = getenv("ATHENA_MHA_PLAIN_ORDER") && atoi(getenv("ATHENA_MHA_PLAIN_ORDER")) != 0;
+    return v;
+}
+
+static bool mha_fwd_halves() {
+    static const bool v = !(getenv("ATHENA_MHA_FWD_HALVES") && atoi(getenv("ATHENA_MHA_FWD_HALVES")) == 0);
+    return v;
+}
+
 #define MHA_MFMA_DISPATCH(KERNEL, GRID, ...)                                                              \
     do {                                                                                                  \
         if (causal) {                                                                                     \
@@ -323,8 +333,34 @@ extern "C" int athena_mha_fwd(const void* q, const void* k, const void* v, int l
         const long heads8 = ((long)B * h + 7) / 8 * 8;
         ATHENA_REQUIRE(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS) < (1L << 31), ATHENA_E_SHAPE, "athena_mha_fwd: too many blocks");
         const dim3 grid((unsigned)(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS)));
-        MHA_MFMA_DISPATCH(mha_fwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse, B * h);
+        // two halves of the key blocks side by side in one workgroup where there are at least three
+        // blocks (and the two sets of images fit: head size up to 64)
+        const bool halves = dk <= 64 && (Tk + AM_ROWS - 1) / AM_ROWS >= 3 && mha_fwd_halves();
+#define MHA_FWD(DKV, CA)                                                                                          \
+    do {                                                                                                          \
+        if (halves)                                                                                               \
+            ATHENA_LAUNCH((mha_fwd_mfma_kernel<DKV, CA, 2>), grid, dim3(512), 0, s, (const bf16_t*)q, (const bf16_t*)k, \
+                          (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse,  \
+                          mha_plain_order() ? -(B * h) : B * h);                                                  \
+        else                                                                                                      \
+            ATHENA_LAUNCH((mha_fwd_mfma_kernel<DKV, CA, 1>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k, \
+                          (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse,  \
+                          mha_plain_order() ? -(B * h) : B * h);                                                  \
+    } while (0)
+        if (causal) {
+            if (dk == 32) MHA_FWD(32, true);
+            else if (dk == 64) MHA_FWD(64, true);
+            else ATHENA_LAUNCH((mha_fwd_mfma_kernel<128, true, 1>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse,
+                               mha_plain_order() ? -(B * h) : B * h);
+        } else {
+            if (dk == 32) MHA_FWD(32, false);
+            else if (dk == 64) MHA_FWD(64, false);
+            else ATHENA_LAUNCH((mha_fwd_mfma_kernel<128, false, 1>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, (bf16_t*)out, ldo, lse,
+                               mha_plain_order() ? -(B * h) : B * h);
+        }
+#undef MHA_FWD
         ATHENA_CHECK_LAUNCH("athena_mha_fwd");
         return ATHENA_OK;
     }
@@ -367,7 +403,7 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
         const dim3 grid((unsigned)(heads8 * per_head));
         MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
                           key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
-                          (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 0);
+                          (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, mha_plain_order() ? -(B * h) : B * h, 0);
         ATHENA_CHECK_LAUNCH("athena_mha_bwd");
         return ATHENA_OK;
     }

@@ -106,6 +106,11 @@ __device__ __forceinline__ float att_key_bias(const uint8_t* __restrict__ key_ma
 // that differ by multiples of eight: they run on one XCD at about the same time and the head's
 // operands come through that one L2 once.  The grid is nW * roundup(heads, 8); false = padding.
 __device__ __forceinline__ bool att_xcd_map(int nW, int heads, int& w, int& head) {
+    if (heads < 0) {        // (plain order, for measurements: consecutive workgroups = the blocks of a head)
+        head = blockIdx.x / nW;
+        w = blockIdx.x - head * nW;
+        return head < -heads;
+    }
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     head = (slot / nW) * 8 + xcd;
     w = slot - (slot / nW) * nW;
@@ -113,17 +118,22 @@ __device__ __forceinline__ bool att_xcd_map(int nW, int heads, int& w, int& head
 }
 
 // ---------------------------------------------------------------- forward
-template <int DK, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+// KH = 2: eight waves, the upper four take the second half of the key blocks of the same 64 queries,
+// and the two partial results (running maximum, sum and unnormalised output per query) are merged
+// through LDS at the end.  A launch takes as long as one workgroup's chain of key blocks (there are
+// about as many workgroups as the chip holds at once), so halving the chain shortens the launch.
+template <int DK, bool CAUSAL, int KH>
+__global__ __launch_bounds__(256 * KH) void mha_fwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
                                                            const uint8_t* __restrict__ key_mask, int causal, int h,
                                                            int Tq, int Tk, float scale, bf16_t* __restrict__ out,
                                                            int ldo, float* __restrict__ lse, int heads) {
     constexpr int KS = DK / 32, NT = DK / 16;
-    __shared__ __attribute__((aligned(16))) bf16_t sK[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) bf16_t sV[2][AM_ROWS * DK];
-    __shared__ __attribute__((aligned(16))) float sM[2][AM_ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    __shared__ __attribute__((aligned(16))) bf16_t sK[KH][2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) bf16_t sV[KH][2][AM_ROWS * DK];
+    __shared__ __attribute__((aligned(16))) float sM[KH][2][AM_ROWS];
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+    const int kh = KH == 2 ? (int)(threadIdx.x >> 8) : 0;
     int qblk, head;
     if (!att_xcd_map((Tq + AM_ROWS - 1) / AM_ROWS, heads, qblk, head)) return;
     const int b = head / h, hh = head % h;
@@ -142,17 +152,22 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 
     AttStage<DK> stK, stV;
     float mflag = 0.f;
-    const int nblk = (Tk + AM_ROWS - 1) / AM_ROWS;
-    stK.load(kb, ldk, 0, Tk, tid);
-    stV.load(vb, ldv, 0, Tk, tid);
-    if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, tid);
-    stK.store(sK[0], tid);
-    stV.store(sV[0], tid);
-    if (tid < AM_ROWS) sM[0][tid] = mflag;
+    const int nblk_all = (Tk + AM_ROWS - 1) / AM_ROWS;
+    // this half's key blocks: [blk0, blk0 + nblk); both halves run the same number of trips (the
+    // barriers are the workgroup's), a half without a block in a trip works on keys past the end
+    const int per = (nblk_all + KH - 1) / KH;
+    const int blk0 = kh * per;
+    const int nblk = per;
+    stK.load(kb, ldk, blk0 * AM_ROWS, Tk, tid);
+    stV.load(vb, ldv, blk0 * AM_ROWS, Tk, tid);
+    if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, blk0 * AM_ROWS + tid);
+    stK.store(sK[kh][0], tid);
+    stV.store(sV[kh][0], tid);
+    if (tid < AM_ROWS) sM[kh][0][tid] = mflag;
     __syncthreads();
 
     for (int blk = 0; blk < nblk; ++blk) {
-        const int cur = blk & 1, j0 = blk * AM_ROWS;
+        const int cur = blk & 1, j0 = (blk0 + blk) * AM_ROWS;
         const bool more = blk + 1 < nblk;
         if (more) {
             stK.load(kb, ldk, j0 + AM_ROWS, Tk, tid);
@@ -166,13 +181,13 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
             s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sK[cur], 16 * jt, ks, lane), qf[ks],
+                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sK[kh][cur], 16 * jt, ks, lane), qf[ks],
                                                                 s[jt], 0, 0, 0);
         }
         float tmax = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            const float4 b4 = *(const float4*)&sM[cur][16 * jt + 4 * g];
+            const float4 b4 = *(const float4*)&sM[kh][cur][16 * jt + 4 * g];
             const float kb4[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -189,14 +204,15 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
         }
         tmax = rows4_max(tmax);
         const float mn = fmaxf(m, tmax);
-        const float alpha = __expf(m - mn);          // first block: exp(-inf) = 0
+        // (a block of keys past the end leaves the maximum at -inf: nothing to rescale, nothing to add)
+        const float alpha = mn == -INFINITY ? 1.f : __expf(m - mn);          // first block: exp(-inf) = 0
         m = mn;
         float psum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[jt][r] - mn);   // keys past the end: exp(-inf) = 0
+                const float p = mn == -INFINITY ? 0.f : __expf(s[jt][r] - mn);   // keys past the end: exp(-inf) = 0
                 s[jt][r] = p;
                 psum += p;
             }
@@ -210,17 +226,43 @@ __global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    att_frag_tr<DK>(sV[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), pf, o[nt], 0, 0, 0);
+                    att_frag_tr<DK>(sV[kh][cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), pf, o[nt], 0, 0, 0);
         }
         if (more) {
-            stK.store(sK[cur ^ 1], tid);
-            stV.store(sV[cur ^ 1], tid);
-            if (tid < AM_ROWS) sM[cur ^ 1][tid] = mflag;
+            stK.store(sK[kh][cur ^ 1], tid);
+            stV.store(sV[kh][cur ^ 1], tid);
+            if (tid < AM_ROWS) sM[kh][cur ^ 1][tid] = mflag;
         }
         __syncthreads();
     }
     float l = lp;
     l = rows4_sum(l);
+    if constexpr (KH == 2) {
+        // the upper half parks (m, l, o) of its 64 queries in its own first key image (free behind the
+        // last barrier of the loop); the lower half merges: o = o0 e^(m0 - M) + o1 e^(m1 - M)
+        float* park_o = reinterpret_cast<float*>(&sK[1][0][0]);      // [256 threads][NT * 4]: exactly the two images
+        float* park_ml = reinterpret_cast<float*>(&sV[1][0][0]);     // [256 threads][2]
+        static_assert(256 * NT * 4 * 4 <= 2 * AM_ROWS * DK * 2, "the parking space is the half's two key images");
+        if (kh == 1) {
+            float* mine = park_o + tid * (NT * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) *(f32x4_t*)(mine + 4 * nt) = o[nt];
+            park_ml[2 * tid] = m;
+            park_ml[2 * tid + 1] = l;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float* other = park_o + tid * (NT * 4);
+        const float m1 = park_ml[2 * tid], l1 = park_ml[2 * tid + 1];
+        const float M = fmaxf(m, m1);
+        const float a0 = m == -INFINITY ? 0.f : __expf(m - M), a1 = m1 == -INFINITY ? 0.f : __expf(m1 - M);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[nt][r] = o[nt][r] * a0 + other[4 * nt + r] * a1;
+        l = l * a0 + l1 * a1;
+        m = M;
+    }
     if (qi < Tq) {
         const float inv = 1.f / l;
         bf16_t* ob = out + ((long)b * Tq + qi) * ldo + hh * DK + 4 * g;

@@ -7,7 +7,7 @@ from athena_amd.layers.transformer import TransformerEncoderLayer
 from athena_amd.runtime import ParamStore
 
 dev = torch.device("cuda", 0)
-B, T, d, dff = 32, 250, 256, 1024
+B, T, d, dff = 32, int(os.environ.get("STAMP_T", "250")), 256, 1024
 store = ParamStore(torch.bfloat16, device=dev)
 layer = TransformerEncoderLayer(store, "enc", d, 4, dff, 0.1)
 store.finalize(seed=1)
