@@ -41,6 +41,9 @@
 
 #define LT_D 256
 #define LT_THREADS 512
+#ifndef LT_AHEAD2
+#define LT_AHEAD2 0                      // k-blocks of image fragments the 32-row build reads ahead
+#endif
 #define LT_KB 8                          // 32-wide contraction blocks of a 256-wide slice
 // A workgroup owns R = 16 RB rows, RB = 2 (the tall launches: one workgroup per CU at 8000 rows) or 1
 // (row counts that leave most CUs without a workgroup -- a decoder's 1056 rows: the launch takes as
@@ -96,17 +99,33 @@ template <bool ROLL, int RB>
 __device__ __forceinline__ void lt_mul_unit(f32x4_t (&acc)[RB][2], LtUnit& u, const bf16_t* img, int lane,
                                             const bf16_t* __restrict__ next, long next_ld) {
     const int fr = lane & 15, fk = (lane >> 4) * 8;
+    // The image fragments are requested AHEAD k-blocks before the products that use them: read one
+    // k-block at a time and waited for at once, a multiply phase is a chain of eight LDS latencies
+    // with two or four matrix instructions each.  The 16-row build has the registers for all eight
+    // at once (step -16 us); the 32-row build sits at 256 registers, and one or two blocks ahead cost it
+    // more in spills and scheduling fences than they saved (+21 / +49 us per step): it reads as it goes.
+    constexpr int AHEAD = RB == 1 ? LT_KB : LT_AHEAD2;
+    bf16x8_t a[LT_KB][RB];
+#pragma unroll
+    for (int kb = 0; kb < AHEAD; ++kb)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) a[kb][i] = *(const bf16x8_t*)(img + lt_img_off<RB>(16 * i + fr, kb * 32 + fk));
+    if (AHEAD > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < LT_KB; ++kb) {
-        bf16x8_t a[RB];
+        if (kb + AHEAD < LT_KB || AHEAD == 0) {
+            const int kn = kb + AHEAD;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) a[i] = *(const bf16x8_t*)(img + lt_img_off<RB>(16 * i + fr, kb * 32 + fk));
+            for (int i = 0; i < RB; ++i)
+                a[kn][i] = *(const bf16x8_t*)(img + lt_img_off<RB>(16 * i + fr, kn * 32 + fk));
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f[kb][j], a[kb][i], acc[i][j], 0, 0, 0);
         if (ROLL) lt_load_slot(u, kb, next, next_ld);
+        if (AHEAD > 0 && AHEAD < LT_KB) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
