@@ -200,27 +200,45 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t key, uint64_t idx) {
     h ^= h >> 16;
     return h;
 }
-// Dropout decisions are drawn two per hash: element idx takes 16 bits of the hash of idx >> 1 and
-// is kept when they reach the 16-bit threshold.  Returns the multiplier: 0 (dropped) or 1/(1-p).
+// Dropout decisions are drawn four per hash: the elements 4q .. 4q + 3 take the two 16-bit halves of
+// the hash of q and of one more mixing round on top of it (a multiplication and a shift: the three
+// 32-bit multiplications of the hash run at a quarter of the vector rate and are most of its cost),
+// and an element is kept when its 16 bits reach the 16-bit threshold.  Returns the multiplier:
+// 0 (dropped) or 1/(1-p).
+__device__ __forceinline__ uint32_t rng_mix(uint32_t h) {
+    h *= 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
 __device__ __forceinline__ float dropout_mult(uint64_t key, uint64_t idx, uint32_t thresh, float scale) {
-    const uint32_t h = rng_u32(key, idx >> 1);
+    uint32_t h = rng_u32(key, idx >> 2);
+    if (idx & 2) h = rng_mix(h);
     const uint32_t u = (idx & 1) ? (h >> 16) : (h & 0xffffu);
     return u >= thresh ? scale : 0.f;
 }
+// the multipliers of the four consecutive elements base .. base + 3, base a multiple of 4 (same
+// decisions as dropout_mult): one hash
+__device__ __forceinline__ void dropout_mult4(uint64_t key, uint64_t base, uint32_t thresh, float scale, float (&m)[4]) {
+    const uint32_t h0 = rng_u32(key, base >> 2), h1 = rng_mix(h0);
+    m[0] = (h0 & 0xffffu) >= thresh ? scale : 0.f;
+    m[1] = (h0 >> 16) >= thresh ? scale : 0.f;
+    m[2] = (h1 & 0xffffu) >= thresh ? scale : 0.f;
+    m[3] = (h1 >> 16) >= thresh ? scale : 0.f;
+}
 // the multipliers of the eight consecutive elements base .. base + 7 (same decisions as
-// dropout_mult); an even base costs four hashes
+// dropout_mult); a base that is a multiple of 4 costs two hashes
 __device__ __forceinline__ void dropout_mult8(uint64_t key, uint64_t base, uint32_t thresh, float scale,
                                               float (&m)[8]) {
-    if (base & 1) {
+    if (base & 3) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) m[i] = dropout_mult(key, base + i, thresh, scale);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t h = rng_u32(key, (base >> 1) + i);
-        m[2 * i] = (h & 0xffffu) >= thresh ? scale : 0.f;
-        m[2 * i + 1] = (h >> 16) >= thresh ? scale : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        float q[4];
+        dropout_mult4(key, base + 4 * i, thresh, scale, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[4 * i + r] = q[r];
     }
 }
 // 16-bit threshold of a drop probability (0 = dropout off)

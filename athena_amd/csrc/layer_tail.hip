@@ -137,15 +137,10 @@ __device__ __forceinline__ void lt_zero(f32x4_t (&acc)[RB][2]) {
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 }
 
-// dropout multipliers of the four consecutive elements base .. base + 3, base even (same decisions
-// as dropout_mult)
+// dropout multipliers of the four consecutive elements base .. base + 3, base a multiple of 4 (same
+// decisions as dropout_mult)
 __device__ __forceinline__ void lt_dropout4(uint64_t key, uint64_t base, uint32_t thresh, float scale, float (&m)[4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t h = rng_u32(key, (base >> 1) + i);
-        m[2 * i] = (h & 0xffffu) >= thresh ? scale : 0.f;
-        m[2 * i + 1] = (h >> 16) >= thresh ? scale : 0.f;
-    }
+    dropout_mult4(key, base, thresh, scale, m);
 }
 
 __device__ __forceinline__ void lt_store4(bf16_t* p, const float (&v)[4]) {

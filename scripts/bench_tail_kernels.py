@@ -13,7 +13,7 @@ from bench import KernelTimer
 dev = torch.device("cuda", 0)
 B, T, d, dff, L = 32, 250, 256, int(os.environ.get("DFF", "1024")), int(os.environ.get("LAYERS", "4"))
 store = ParamStore(torch.bfloat16, device=dev)
-layers = [TransformerEncoderLayer(store, "encoder.%d" % i, d, 4, dff, 0.1) for i in range(L)]
+layers = [TransformerEncoderLayer(store, "encoder.%d" % i, d, 4, dff, float(os.environ.get("RATE", "0.1"))) for i in range(L)]
 store.finalize(seed=1)
 enc = TransformerEncoder(layers)
 bind_all(enc)

@@ -221,6 +221,42 @@ def test_add_layernorm_dropout(ops):
     assert_close(db, da * torch.round(m), 1e-6, "db = dz * mask")
 
 
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_decisions_are_fair_and_unrelated(ops, p):
+    """The dropout draw hands out four decisions per hash (two from the hash, two from one more mixing
+    round on top of it): over 4 M elements the keep rate is 1 - p, the four positions of a group keep
+    equally often, decisions inside a group and across neighbouring groups are uncorrelated, and two
+    sites or two steps give unrelated masks."""
+    rows, d = 4096, 1024
+    a = torch.zeros(rows, d, device=dev())
+    b = torch.ones(rows, d, device=dev())
+    gam, bet = torch.ones(d, device=dev()), torch.zeros(d, device=dev())
+
+    def mask(seed, step, site):
+        rng = torch.tensor([seed, step], dtype=torch.int64, device=dev())
+        z, _, _, _ = ops.add_layernorm_fwd(a, b, gam, bet, 1e-8, p, rng, site)       # z = dropout(1)
+        return (z != 0).double().cpu()
+
+    m = mask(99, 1, 11)
+    n = m.numel()
+    sd = (p * (1 - p)) ** 0.5
+    assert abs(float(m.mean()) - (1 - p)) < 5 * sd / n ** 0.5 + 2e-5             # (+ the 16-bit threshold's rounding)
+    quads = m.view(-1, 4)
+    for k in range(4):
+        assert abs(float(quads[:, k].mean()) - (1 - p)) < 6 * sd / (n / 4) ** 0.5 + 2e-5, k
+    c = quads - quads.mean(0)
+    cov = (c.t() @ c) / quads.shape[0] / (p * (1 - p))
+    off = cov - torch.diag(torch.diag(cov))
+    assert float(off.abs().max()) < 6 / (n / 4) ** 0.5, off
+    flat = m.view(-1) - m.mean()
+    for lag in (4, 5, 8, d, d + 1):
+        r = float((flat[:-lag] * flat[lag:]).mean()) / (p * (1 - p))
+        assert abs(r) < 6 / n ** 0.5, (lag, r)
+    for other in (mask(99, 2, 11), mask(99, 1, 12), mask(100, 1, 11)):
+        r = float(((other - other.mean()) * flat.view_as(other)).mean()) / (p * (1 - p))
+        assert abs(r) < 6 / n ** 0.5, r
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _attn_ref(q, k, v, key_mask, causal, scale):
     B, Tq, h, dk = q.shape
