@@ -1890,3 +1890,32 @@ extern "C" int athena_group_sum(const float* x, int ngroups, int group, float sc
     ATHENA_CHECK_LAUNCH("athena_group_sum");
     return ATHENA_OK;
 }
+
+// out[0] = sum_i weights[i] * terms[i][0]: the total of a few scalar loss terms as one launch
+#define WSUM_MAX 8
+struct WeightedTerms {
+    const float* term[WSUM_MAX];
+    float weight[WSUM_MAX];
+    int n;
+};
+__global__ void weighted_sum_kernel(WeightedTerms w, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = 0; i < w.n; ++i) s = fmaf(w.weight[i], w.term[i][0], s);
+    out[0] = s;
+}
+
+extern "C" int athena_weighted_sum(const float* const* terms, const float* weights, int n, float* out,
+                                   athena_stream_t stream) {
+    ATHENA_REQUIRE(terms && weights && out && n > 0 && n <= WSUM_MAX, ATHENA_E_SHAPE,
+                   "athena_weighted_sum: 1..%d terms expected, got %d", WSUM_MAX, n);
+    WeightedTerms w = {};
+    w.n = n;
+    for (int i = 0; i < n; ++i) {
+        ATHENA_REQUIRE(terms[i], ATHENA_E_SHAPE, "athena_weighted_sum: term %d is null", i);
+        w.term[i] = terms[i];
+        w.weight[i] = weights[i];
+    }
+    ATHENA_LAUNCH(weighted_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, w, out);
+    ATHENA_CHECK_LAUNCH("athena_weighted_sum");
+    return ATHENA_OK;
+}

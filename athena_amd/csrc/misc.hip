@@ -293,20 +293,54 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t*
     }
 }
 
+// One workgroup per row v of the table: the tokens are scanned 64 per wave, their matches noted as
+// ballot words in LDS, and every thread then walks the matches in token order and sums its
+// columns.  Every row of dE is written (zero where no token has the id), the order of the sum is
+// fixed, and no atomics are needed.
+#define EMB_SEG 8192          // tokens per pass over the ballot words
 template <typename T>
-__global__ void embed_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids, long n, int d, int V,
-                                 float xscale, uint32_t thresh, float dscale, const uint64_t* rng_state,
-                                 uint32_t site, float* __restrict__ dtable) {
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
+                                                        int ntok, int d, int V, float xscale, uint32_t thresh,
+                                                        float dscale, const uint64_t* rng_state, uint32_t site,
+                                                        float* __restrict__ dtable) {
+    __shared__ uint64_t hit[EMB_SEG / 64];
+    const int v = blockIdx.x;
     uint64_t key = 0;
     if (thresh) key = rng_key(rng_state, site);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % d);
-        const long tok = i / d;
-        int id = ids[tok];
-        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-        float v = to_f32<T>(dy[i]) * xscale;
-        if (thresh) v *= dropout_mult(key, (uint64_t)i, thresh, dscale);
-        atomicAdd(dtable + (long)id * d + c, v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c0 = 0; c0 < d; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        float acc = 0.f;
+        for (int t0 = 0; t0 < ntok; t0 += EMB_SEG) {
+            const int seg = min(EMB_SEG, ntok - t0);
+            __syncthreads();
+            for (int w = wave; w * 64 < seg; w += 4) {
+                const int t = t0 + w * 64 + lane;
+                bool m = false;
+                if (t < ntok) {
+                    int id = ids[t];
+                    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+                    m = id == v;
+                }
+                const uint64_t b = __ballot(m);
+                if (lane == 0) hit[w] = b;
+            }
+            __syncthreads();
+            for (int w = 0; w * 64 < seg; ++w) {
+                uint64_t b = hit[w];
+                while (b) {
+                    const int t = t0 + w * 64 + __builtin_ctzll(b);
+                    b &= b - 1;
+                    if (c < d) {
+                        const long i = (long)t * d + c;
+                        float g = to_f32<T>(dy[i]) * xscale;
+                        if (thresh) g *= dropout_mult(key, (uint64_t)i, thresh, dscale);
+                        acc += g;
+                    }
+                }
+            }
+        }
+        if (c < d) dtable[(long)v * d + c] = acc;
     }
 }
 
@@ -336,16 +370,15 @@ extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L
                                 float* dtable, athena_stream_t stream) {
     ATHENA_REQUIRE(dy && ids && dtable && B > 0 && L > 0 && d > 0 && V > 0, ATHENA_E_SHAPE, "athena_embed_bwd: bad arguments");
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_embed_bwd: dropout args");
-    const long n = (long)B * L * d;
+    ATHENA_REQUIRE((long)B * L < (1L << 31) - EMB_SEG, ATHENA_E_SHAPE, "athena_embed_bwd: too many tokens");
+    const int ntok = B * L;
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    long blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == ATHENA_BF16)
-        ATHENA_LAUNCH(embed_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        ATHENA_LAUNCH(embed_bwd_kernel<bf16_t>, dim3((unsigned)V), dim3(256), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     else if (dtype == ATHENA_F32)
-        ATHENA_LAUNCH(embed_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy, ids, n, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        ATHENA_LAUNCH(embed_bwd_kernel<float>, dim3((unsigned)V), dim3(256), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     else
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_bwd: dtype");
     ATHENA_CHECK_LAUNCH("athena_embed_bwd");

@@ -617,9 +617,17 @@ class DenseFn(torch.autograd.Function):
     copying it into a fresh padded tensor."""
 
     @staticmethod
-    def forward(ctx, x, dense, kernel, bias):
+    def forward(ctx, x, dense, kernel, bias, joins_memory_grad=False):
         B, T, K = x.shape
         N = dense.out_features
+        # ``x`` may be the encoder output that decoder layers of this forward pass attend to (they have
+        # entered its gradient slot by now).  Inside a solver step, whose total loss reaches ``x`` through
+        # them too, this projection's dx then goes into the buffer they share instead of into a tensor
+        # of its own that autograd would add with one more launch.
+        ctx.mem_slot = None
+        if joins_memory_grad and ctx.needs_input_grad[0] and ops.root_gradient_is_one() and \
+                getattr(x, "_athena_grad_slot", None) is not None:
+            ctx.mem_slot = _MemoryGrad.enter(x)
         Np = ops.roundup(N, 8)
         x2 = x.reshape(B * T, K)
         # the padding columns [N, Np) stay unwritten: nothing reads them (the returned view ends at N,
@@ -655,9 +663,21 @@ class DenseFn(torch.autograd.Function):
             ops.cast(dy, g)
             dy = g
         lin_bwd_w(x2, dy, M, dense, K, Np)
-        dx = lin_bwd_x(dy, M, dense, Np)
+        slot, ctx.mem_slot = ctx.mem_slot, None
         ctx.x2 = None
-        return dx.view(B, T, K), None, None, None
+        if slot is not None and slot["buf"] is None and dy.dtype == x2.dtype:
+            # first to arrive: the shared buffer starts as this product
+            slot["buf"] = dx = lin_bwd_x(dy, M, dense, Np)
+            return (dx.view(B, T, K) if _MemoryGrad.leave(slot) else None), None, None, None, None
+        dx = lin_bwd_x(dy, M, dense, Np)
+        if slot is not None:
+            if slot["buf"].dtype == dx.dtype:
+                dx = slot["buf"].add_(dx)
+                if not _MemoryGrad.leave(slot):
+                    dx = None
+            elif _MemoryGrad.leave(slot):
+                dx = dx + slot["buf"].to(dx.dtype)
+        return (None if dx is None else dx.view(B, T, K)), None, None, None, None
 
 
 class XNetFn(torch.autograd.Function):
@@ -789,8 +809,7 @@ class YNetFn(torch.autograd.Function):
         net, ids, p = ctx.net, ctx.ids, ctx.p
         st = net.store
         B, L = ids.shape
-        g = net.embedding.grad
-        g.zero_()
+        g = net.embedding.grad          # every row is written
         ops.embed_bwd(dout.contiguous(), ids, B, L, net.d_model, net.num_class, net.xscale, p, st.rng_state,
                       net.site_drop, g)
         return None, None, None, None

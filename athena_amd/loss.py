@@ -88,6 +88,38 @@ class _CTCLossFn(torch.autograd.Function):
         return grad[..., :V], None, None, None, None, None, None, None
 
 
+class _WeightedTotalFn(torch.autograd.Function):
+    """total = sum_i weights[i] * terms[i] as one launch.  Inside a solver step (whose root gradient is
+    one) the backward pass hands each term its weight as a constant that already sits on the device,
+    so that no kernel runs at all."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        out = torch.empty(1, dtype=torch.float32, device=terms[0].device)
+        ops.weighted_sum([t.detach().reshape(1) for t in terms], weights, out)
+        ctx.weights = weights
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = []
+        for w in ctx.weights:
+            c = ops.const_scalar(gout.device, w) if ops.root_gradient_is_one() else None
+            grads.append(c if c is not None else gout * w)
+        return (None,) + tuple(grads)
+
+
+def weighted_total(terms, weights):
+    """sum_i weights[i] * terms[i] for 0-dim fp32 loss tensors on one GPU (anything else: plain torch)."""
+    if 0 < len(terms) <= 8 and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 0 and
+                                   t.dtype == torch.float32 for t in terms):
+        return _WeightedTotalFn.apply(tuple(float(w) for w in weights), *terms)
+    total = None
+    for t, w in zip(terms, weights):
+        total = t * w if total is None else total + t * w
+    return total
+
+
 class CTCLoss:
     """CTC loss: tf.nn.ctc_loss on batch-major logits with dense labels, then the batch mean
     (reference athena/loss.py:24-46)."""

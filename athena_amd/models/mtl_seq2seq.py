@@ -5,7 +5,7 @@ import os
 import torch
 
 from ..layers.commons import Dense, bind_all
-from ..loss import CTCLoss
+from ..loss import CTCLoss, weighted_total
 from ..metrics import CTCAccuracy
 from ..runtime import ParamStore
 from ..utils.hparam import register_and_parse_hparams
@@ -67,7 +67,8 @@ class MtlTransformerCtc(BaseModel):
 
     def call(self, samples, training=None):
         attention_logits, encoder_output = self.model(samples, training=training)
-        ctc_logits = SpeechTransformer._project(self.decoder, encoder_output)
+        # the encoder output also feeds the attention decoder: its gradient from here joins theirs
+        ctc_logits = SpeechTransformer._project(self.decoder, encoder_output, joins_memory_grad=True)
         return attention_logits, ctc_logits
 
     def get_loss(self, outputs, samples, training=None):
@@ -81,11 +82,8 @@ class MtlTransformerCtc(BaseModel):
         self.metric(ctc_logits, samples, logit_length)
         main_loss, metrics = self.model.get_loss(attention_logits, samples, training=training)
         mtl_weight = self.hparams.mtl_weight
-        if isinstance(main_loss, torch.Tensor) and isinstance(extra_loss, torch.Tensor):
-            # mtl_weight * main + (1 - mtl_weight) * extra as one kernel (mtl_seq2seq.py:95)
-            loss = torch.lerp(extra_loss, main_loss, float(mtl_weight))
-        else:
-            loss = mtl_weight * main_loss + (1.0 - mtl_weight) * extra_loss
+        # mtl_weight * main + (1 - mtl_weight) * extra as one kernel (mtl_seq2seq.py:95)
+        loss = weighted_total([main_loss, extra_loss], [mtl_weight, 1.0 - mtl_weight])
         metrics[self.metric.name] = LazyMetric(self.metric)
         return loss, metrics
 

@@ -148,9 +148,11 @@ class SpeechTransformer(BaseModel):
         return y
 
     @staticmethod
-    def _project(dense, h):
-        """Dense(V): fp32 logits [B, T, V] as a view of rows padded to a multiple of 8 columns."""
-        y = DenseFn.apply(h, dense, dense.kernel, dense.bias)
+    def _project(dense, h, joins_memory_grad=False):
+        """Dense(V): fp32 logits [B, T, V] as a view of rows padded to a multiple of 8 columns.
+        ``joins_memory_grad``: ``h`` is the encoder output the decoder layers attend to, and the
+        caller's total loss reaches it through them as well."""
+        y = DenseFn.apply(h, dense, dense.kernel, dense.bias, joins_memory_grad)
         # the projection's backward pass consumes bf16: the loss kernels may write their gradient so
         y._athena_accepts_bf16_grad = h.dtype == torch.bfloat16
         return y

@@ -799,6 +799,7 @@ def embed_fwd(table, ids, pe, B, L, d, V, xscale, drop_p, rng_state, site, y):
 
 
 def embed_bwd(dy, ids, B, L, d, V, xscale, drop_p, rng_state, site, dtable):
+    """dtable [V, d] = the gradient of the embedding table: every row is written (no zeroing before)."""
     lib = _lib.load()
     if dtable.numel() != V * d or ids.numel() != B * L or dy.numel() != B * L * d:
         raise RuntimeError("athena_amd.embed_bwd: bad operands")
@@ -1073,6 +1074,33 @@ def take_bf16_grad(dy):
         return None
     entry = _BF16_GRADS.pop(dy.data_ptr(), None)
     return None if entry is None else entry[1]
+
+
+def weighted_sum(terms, weights, out):
+    """out[0] = sum_i weights[i] * terms[i][0] (fp32 scalars on the device, host weights), one launch."""
+    n = len(terms)
+    if n != len(weights) or not 0 < n <= 8 or out.dtype != torch.float32 or out.numel() < 1 or \
+            any(t.dtype != torch.float32 or t.numel() != 1 or t.device != out.device for t in terms):
+        raise RuntimeError("athena_amd.weighted_sum: 1..8 fp32 scalars on the device of out expected")
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+    w = (ctypes.c_float * n)(*[float(x) for x in weights])
+    _lib.check(_lib.load().athena_weighted_sum(ptrs, w, n, _ptr(out), _stream()), "athena_weighted_sum")
+
+
+_CONST_SCALARS = {}
+
+
+def const_scalar(device, value):
+    """A 0-dim fp32 tensor holding ``value`` that lives for good (one per device and value), or None
+    while a stream of this thread is recording and the tensor does not exist yet: memory allocated
+    during a recording belongs to the graph and must not outlive it."""
+    key = (str(device), float(value))
+    t = _CONST_SCALARS.get(key)
+    if t is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return None
+        t = _CONST_SCALARS[key] = torch.full((), float(value), dtype=torch.float32, device=device)
+    return t
 
 
 def axpby(a, x, b, y):

@@ -68,7 +68,10 @@ class BaseSolver:
             outputs = self.model(samples, training=True)
             loss, metrics = self.model.get_loss(outputs, samples, training=True)
             total_loss = sum(list(loss.values())) if isinstance(loss, dict) else loss
-            total_loss.backward()
+            # (the root gradient is a constant one that already sits on the device: no fill per step)
+            one = ops.const_scalar(total_loss.device, 1.0) if total_loss.is_cuda and total_loss.dim() == 0 and \
+                total_loss.dtype == torch.float32 else None
+            total_loss.backward(one)
         return loss, metrics
 
     def _reduce_gradients(self):

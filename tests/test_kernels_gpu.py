@@ -617,7 +617,8 @@ def test_embedding_and_pe(ops, cd):
     dy = torch.randn(B, L, d, generator=g, dtype=torch.float64)
     dt_ref = torch.zeros(V, d, dtype=torch.float64)
     dt_ref.index_add_(0, ids.long().view(-1), (rounded(dy, cd) * xs).view(-1, d))
-    dtab = torch.zeros(V, d, dtype=torch.float32, device=dev())
+    # every row is written, rows no token points at included: what the buffer held does not matter
+    dtab = torch.full((V, d), 7.0, dtype=torch.float32, device=dev())
     ops.embed_bwd(to_cd(dy, cd), ids.to(dev()), B, L, d, V, xs, 0.0, None, 0, dtab)
     assert_close(dtab, dt_ref, 1e-5, "embedding grad")
     x = torch.randn(B, L, d, generator=g, dtype=torch.float64)
@@ -630,6 +631,57 @@ def test_embedding_and_pe(ops, cd):
     ops.dropout_bwd(to_cd(dy, cd), 1.0, 0.0, None, 0, to_cd(yv, cd), dx)
     yr = rounded(yv, cd)
     assert_close(dx, rounded(dy, cd) * ((yr > 0) & (yr < 6)).double(), 1e-6, "relu6 gate")
+
+
+def test_embedding_grad_many_tokens_with_dropout(ops):
+    """More tokens than one pass over the match words holds, ids outside the table (clamped like the
+    forward pass clamps them), a width that is no multiple of the workgroup, and the dropout
+    decisions of the forward pass: grad = sum over tokens of dy * (y / (table * xs + pe)), i.e. the
+    multiplier each element of the forward output shows.  Two runs agree bit for bit."""
+    B, L, d, V = 5, 1800, 320, 37
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(-2, V + 2, (B, L), generator=g).to(torch.int32)
+    table = (torch.rand(V, d, generator=g) + 1.0)
+    pe = torch.zeros(L, d)
+    rng = torch.tensor([1234, 5], dtype=torch.int64, device=dev())
+    y = torch.empty(B, L, d, dtype=torch.float32, device=dev())
+    ops.embed_fwd(table.to(dev()), ids.to(dev()), pe.to(dev()), B, L, d, V, 2.0, 0.25, rng, 9, y)
+    cl = ids.long().clamp(0, V - 1)
+    mult = (y.cpu().double() / (table.double()[cl] * 2.0))
+    assert bool(((mult == 0) | ((mult - 1 / 0.75).abs() < 1e-5)).all())
+    mult = (mult != 0).double() / 0.75
+    dy = torch.randn(B, L, d, generator=g)
+    want = torch.zeros(V, d, dtype=torch.float64)
+    want.index_add_(0, cl.view(-1), (dy.double() * mult * 2.0).view(-1, d))
+    got = [torch.full((V, d), float("nan"), dtype=torch.float32, device=dev()) for _ in range(2)]
+    for t in got:
+        ops.embed_bwd(dy.to(dev()), ids.to(dev()), B, L, d, V, 2.0, 0.25, rng, 9, t)
+    assert_close(got[0], want, 1e-5, "embedding grad, many tokens")
+    assert torch.equal(got[0], got[1])
+
+
+def test_weighted_total_of_loss_terms(ops):
+    """mtl_weight * main + (1 - mtl_weight) * extra (reference athena/models/mtl_seq2seq.py:95) as one
+    launch, and the gradients it hands its terms: inside a solver step constants, outside products
+    with whatever arrives."""
+    from athena_amd.loss import weighted_total
+    a = torch.tensor(3.25, device=dev(), requires_grad=True)
+    b = torch.tensor(-1.5, device=dev(), requires_grad=True)
+    for w in (0.5, 0.3, 1.0, 0.0):
+        total = weighted_total([a, b], [w, 1.0 - w])
+        assert abs(float(total) - (w * 3.25 + (1.0 - w) * -1.5)) < 1e-6
+        ga, gb = torch.autograd.grad(total * 2.0, [a, b])
+        assert abs(float(ga) - 2.0 * w) < 1e-7 and abs(float(gb) - 2.0 * (1.0 - w)) < 1e-7
+        with ops.bf16_grad_handover():
+            total = weighted_total([a, b], [w, 1.0 - w])
+            ga, gb = torch.autograd.grad(total, [a, b], ops.const_scalar(total.device, 1.0))
+        assert float(ga) == np.float32(w) and float(gb) == np.float32(1.0 - w)
+    out = torch.empty(1, device=dev())
+    terms = [torch.tensor([float(i)], device=dev()) for i in range(8)]
+    ops.weighted_sum(terms, [0.5] * 8, out)
+    assert float(out) == 14.0
+    with pytest.raises(RuntimeError):
+        ops.weighted_sum(terms + terms[:1], [0.5] * 9, out)
 
 
 # ------------------------------------------------------------------------------------------ CTC

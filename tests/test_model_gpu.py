@@ -5,6 +5,7 @@ its largest element), parameters after optimizer steps within 1e-5.  bf16 mode: 
 1e-2 absolute of the fp32 oracle.
 """
 import copy
+import math
 import os
 
 import pytest
@@ -386,7 +387,23 @@ def test_bf16_gradient_handover_matches_fp32_gradient_path():
         loss2.backward()
     assert not ops._BF16_GRADS, "a registered bf16 gradient buffer was not consumed"
     assert float(loss2) == float(loss)
-    assert torch.equal(model.store.grads, plain)
+    # Everything behind the encoder output gets the very same gradient.  The encoder output's own
+    # gradient is a bf16 sum of seven terms (six cross-attentions and the CTC head) that the solver step
+    # adds in another order -- the CTC head's first, into the buffer the decoder layers share -- so the
+    # encoder and the front end agree to the rounding of that sum only.
+    # (a tensor whose gradient is noise around zero, like the bias of a key projection, is held against
+    # the size of the front gradients as a whole)
+    st = model.store
+    front = [s for s in st.train_slots if s.name.startswith(("encoder.", "x_net."))]
+    floor = 0.02 * math.sqrt(sum(float(plain[s.offset:s.offset + s.numel].square().sum()) for s in front))
+    for slot in st.train_slots:
+        a = st.grads[slot.offset:slot.offset + slot.numel]
+        b = plain[slot.offset:slot.offset + slot.numel]
+        if slot in front:
+            err = float((a - b).norm()) / max(float(b.norm()), floor)
+            assert err < 3e-2, (slot.name, err)
+        else:
+            assert torch.equal(a, b), slot.name
 
 
 def test_training_entry_point_epochs_checkpoints_and_resume(tmp_path):
