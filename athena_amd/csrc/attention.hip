@@ -304,6 +304,21 @@ static bool mha_fwd_halves() {
         }                                                                                                 \
     } while (0)
 
+// backward launch: RS sets of 16 queries per wave of a dQ workgroup (two only for head sizes up to 64
+// without a causal band: with one the two-set build spills)
+#define MHA_BWD_DISPATCH(RS, GRID, ...)                                                                          \
+    do {                                                                                                         \
+        if (causal) {                                                                                            \
+            if (dk == 32) ATHENA_LAUNCH((mha_bwd_mfma_kernel<32, true, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);       \
+            else if (dk == 64) ATHENA_LAUNCH((mha_bwd_mfma_kernel<64, true, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);  \
+            else ATHENA_LAUNCH((mha_bwd_mfma_kernel<128, true, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);               \
+        } else {                                                                                                 \
+            if (dk == 32) ATHENA_LAUNCH((mha_bwd_mfma_kernel<32, false, RS>), GRID, dim3(256), 0, s, __VA_ARGS__);     \
+            else if (dk == 64) ATHENA_LAUNCH((mha_bwd_mfma_kernel<64, false, RS>), GRID, dim3(256), 0, s, __VA_ARGS__); \
+            else ATHENA_LAUNCH((mha_bwd_mfma_kernel<128, false, 1>), GRID, dim3(256), 0, s, __VA_ARGS__);              \
+        }                                                                                                        \
+    } while (0)
+
 #define MHA_DISPATCH(KERNEL, T, ...)                                                                          \
     do {                                                                                                      \
         switch (dk) {                                                                                         \
@@ -386,24 +401,33 @@ extern "C" int athena_mha_bwd(const void* q, const void* k, const void* v, int l
     dim3 gd((unsigned)((total + 255) / 256));
     if (mha_mfma_ok(dtype, dk, {ldq, ldk, ldv, ldo, lddq, lddk, lddv}, {q, k, v, out, dout, dq, dk_, dv})) {
         const long heads8 = ((long)B * h + 7) / 8 * 8;
-        const long per_head = (Tq + AM_ROWS - 1) / AM_ROWS + (Tk + AM_ROWS - 1) / AM_ROWS;
-        ATHENA_REQUIRE(heads8 * per_head < (1L << 31), ATHENA_E_SHAPE, "athena_mha_bwd: too many blocks");
+        // dQ workgroups of 128 queries (two sets of 16 per wave) once there are more than 96 of them
+        static const int rs_env = getenv("ATHENA_MHA_BWD_RS") ? atoi(getenv("ATHENA_MHA_BWD_RS")) : 0;
+        const int rs = (dk > 64 || causal) ? 1 : (rs_env == 1 || rs_env == 2) ? rs_env : (Tq > 96 ? 2 : 1);
+        const long nqb = (Tq + AM_ROWS * rs - 1) / (AM_ROWS * rs), nkb = (Tk + AM_ROWS - 1) / AM_ROWS;
+        ATHENA_REQUIRE(heads8 * (nqb + nkb) < (1L << 31), ATHENA_E_SHAPE, "athena_mha_bwd: too many blocks");
         static const bool split = getenv("ATHENA_MHA_BWD_SPLIT") && atoi(getenv("ATHENA_MHA_BWD_SPLIT")) != 0;
+#define MHA_BWD_ARGS(HEADS, ONLY)                                                                                   \
+    (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale,        \
+        (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta, (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, \
+        lddv, HEADS, ONLY
         if (split) {
-            const dim3 gk((unsigned)(heads8 * ((Tk + AM_ROWS - 1) / AM_ROWS))), gq((unsigned)(heads8 * ((Tq + AM_ROWS - 1) / AM_ROWS)));
-            MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, gk, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                              key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
-                              (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 1);
-            MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, gq, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                              key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
-                              (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, B * h, 2);
+            const dim3 gk((unsigned)(heads8 * nkb)), gq((unsigned)(heads8 * nqb));
+            if (rs == 2) {
+                MHA_BWD_DISPATCH(2, gk, MHA_BWD_ARGS(B * h, 1));
+                MHA_BWD_DISPATCH(2, gq, MHA_BWD_ARGS(B * h, 2));
+            } else {
+                MHA_BWD_DISPATCH(1, gk, MHA_BWD_ARGS(B * h, 1));
+                MHA_BWD_DISPATCH(1, gq, MHA_BWD_ARGS(B * h, 2));
+            }
             ATHENA_CHECK_LAUNCH("athena_mha_bwd");
             return ATHENA_OK;
         }
-        const dim3 grid((unsigned)(heads8 * per_head));
-        MHA_MFMA_DISPATCH(mha_bwd_mfma_kernel, grid, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv,
-                          key_mask, causal, h, Tq, Tk, scale, (const bf16_t*)out, (const bf16_t*)dout, ldo, lse, delta,
-                          (bf16_t*)dq, (bf16_t*)dk_, (bf16_t*)dv, lddq, lddk, lddv, mha_plain_order() ? -(B * h) : B * h, 0);
+        const dim3 grid((unsigned)(heads8 * (nqb + nkb)));
+        const int heads = mha_plain_order() ? -(B * h) : B * h;
+        if (rs == 2) MHA_BWD_DISPATCH(2, grid, MHA_BWD_ARGS(heads, 0));
+        else MHA_BWD_DISPATCH(1, grid, MHA_BWD_ARGS(heads, 0));
+#undef MHA_BWD_ARGS
         ATHENA_CHECK_LAUNCH("athena_mha_bwd");
         return ATHENA_OK;
     }

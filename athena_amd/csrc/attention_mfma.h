@@ -289,7 +289,11 @@ struct AttBwdLds {
     float y[2][AM_ROWS];            // -, or delta
 };
 
-template <int DK, bool CAUSAL>
+// dQ: a wave owns RS sets of 16 queries (a workgroup 64 * RS), keys / values streamed.  With two sets a
+// fragment of the streamed side read from LDS serves two products, and a head has half as many of
+// these workgroups: together with its dK/dV workgroups they then fit the chip in one go at three
+// waves per SIMD.
+template <int DK, bool CAUSAL, int RS>
 __device__ __forceinline__ void mha_bwd_dq_body(AttBwdLds<DK>& sm, int qblk, int head, const bf16_t* __restrict__ q,
                                                 const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq,
                                                 int ldk, int ldv, const uint8_t* __restrict__ key_mask, int causal,
@@ -305,25 +309,30 @@ __device__ __forceinline__ void mha_bwd_dq_body(AttBwdLds<DK>& sm, int qblk, int
     const int b = head / h, hh = head % h;
     const bf16_t* kb = k + (long)b * Tk * ldk + hh * DK;
     const bf16_t* vb = v + (long)b * Tk * ldv + hh * DK;
-    const int qi = qblk * AM_ROWS + wave * 16 + li;
-    const bool qok = qi < Tq;
+    const int qi0 = qblk * (AM_ROWS * RS) + wave * (16 * RS) + li;        // set rs: qi0 + 16 rs
 
-    bf16x8_t qf[KS], dof[KS];
-    float del_i = 0.f;
+    bf16x8_t qf[RS][KS], dof[RS][KS];
+    float del_i[RS], lse_i[RS];
+    f32x4_t acc[RS][NT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = att_load8(q + (long)b * Tq * ldq + hh * DK, qi, Tq, ldq, 32 * ks + 8 * g);
-        dof[ks] = att_load8(dout + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
-        const bf16x8_t of = att_load8(out + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+    for (int rs = 0; rs < RS; ++rs) {
+        const int qi = qi0 + 16 * rs;
+        float d = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) del_i += (float)dof[ks][r] * (float)of[r];
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[rs][ks] = att_load8(q + (long)b * Tq * ldq + hh * DK, qi, Tq, ldq, 32 * ks + 8 * g);
+            dof[rs][ks] = att_load8(dout + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+            const bf16x8_t of = att_load8(out + (long)b * Tq * ldo + hh * DK, qi, Tq, ldo, 32 * ks + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) d += (float)dof[rs][ks][r] * (float)of[r];
+        }
+        d = rows4_sum(d);
+        del_i[rs] = d;
+        lse_i[rs] = qi < Tq ? lse[((long)b * h + hh) * Tq + qi] : INFINITY;
+        if (qi < Tq && g == 0) delta[((long)b * h + hh) * Tq + qi] = d;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rs][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    del_i = rows4_sum(del_i);
-    const float lse_i = qok ? lse[((long)b * h + hh) * Tq + qi] : INFINITY;
-    if (qok && g == 0) delta[((long)b * h + hh) * Tq + qi] = del_i;
-    f32x4_t acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     AttStage<DK> stK, stV;
     float mflag = 0.f;
@@ -344,43 +353,60 @@ __device__ __forceinline__ void mha_bwd_dq_body(AttBwdLds<DK>& sm, int qblk, int
             stV.load(vb, ldv, j0 + AM_ROWS, Tk, tid);
             if (tid < AM_ROWS) mflag = att_key_bias(key_mask, b, Tk, j0 + AM_ROWS + tid);
         }
-        f32x4_t s[4], dp[4];
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            s[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            dp[jt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sK[cur], 16 * jt, ks, lane), qf[ks],
-                                                                s[jt], 0, 0, 0);
-                dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sV[cur], 16 * jt, ks, lane), dof[ks],
-                                                                 dp[jt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const float4 b4 = *(const float4*)&sM[cur][16 * jt + 4 * g];
-            const float kb4[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float bias = kb4[r];
-                if constexpr (CAUSAL) {
-                    const int kj = j0 + 16 * jt + 4 * g + r;
-                    bias = (kj > qi + causal - 1 && bias == 0.f) ? -1e9f : bias;
-                }
-                const float sv = s[jt][r] * scale + bias;
-                const float p = __expf(sv - lse_i);
-                s[jt][r] = p * (dp[jt][r] - del_i) * scale;     // dS
-            }
-        }
-        // dq^T[d][query] += sum_key k[key][d] dS[query][key]
+        // 32 keys at a time (two 16-key tiles: the contraction of one step of the dq product)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8_t dsf = att_pack(s[2 * kk], s[2 * kk + 1]);
+            f32x4_t s[RS][2], dp[RS][2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    att_frag_tr<DK>(sK[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane), dsf, acc[nt], 0, 0, 0);
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int jt = 2 * kk + h2;
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs) {
+                    s[rs][h2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    dp[rs][h2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t kfr = att_frag_rows<DK>(sK[cur], 16 * jt, ks, lane);
+                    const bf16x8_t vfr = att_frag_rows<DK>(sV[cur], 16 * jt, ks, lane);
+#pragma unroll
+                    for (int rs = 0; rs < RS; ++rs) {
+                        s[rs][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[rs][ks], s[rs][h2], 0, 0, 0);
+                        dp[rs][h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[rs][ks], dp[rs][h2], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int jt = 2 * kk + h2;
+                const float4 b4 = *(const float4*)&sM[cur][16 * jt + 4 * g];
+                const float kb4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float bias = kb4[r];
+                        if constexpr (CAUSAL) {
+                            const int kj = j0 + 16 * jt + 4 * g + r;
+                            bias = (kj > qi0 + 16 * rs + causal - 1 && bias == 0.f) ? -1e9f : bias;
+                        }
+                        const float sv = s[rs][h2][r] * scale + bias;
+                        const float p = __expf(sv - lse_i[rs]);
+                        s[rs][h2][r] = p * (dp[rs][h2][r] - del_i[rs]) * scale;     // dS
+                    }
+                }
+            }
+            // dq^T[d][query] += sum_key k[key][d] dS[query][key]
+            bf16x8_t dsf[RS];
+#pragma unroll
+            for (int rs = 0; rs < RS; ++rs) dsf[rs] = att_pack(s[rs][0], s[rs][1]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8_t ktr = att_frag_tr<DK>(sK[cur], 32 * kk, 32 * kk + 16, 16 * nt, lane);
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs)
+                    acc[rs][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf[rs], acc[rs][nt], 0, 0, 0);
+            }
         }
         if (more) {
             stK.store(sK[cur ^ 1], tid);
@@ -389,12 +415,17 @@ __device__ __forceinline__ void mha_bwd_dq_body(AttBwdLds<DK>& sm, int qblk, int
         }
         __syncthreads();
     }
-    if (qok) {
-        bf16_t* ob = dq + ((long)b * Tq + qi) * lddq + hh * DK + 4 * g;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bf16x4_t w = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
-            *(bf16x4_t*)(ob + 16 * nt) = w;
+    for (int rs = 0; rs < RS; ++rs) {
+        const int qi = qi0 + 16 * rs;
+        if (qi < Tq) {
+            bf16_t* ob = dq + ((long)b * Tq + qi) * lddq + hh * DK + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x4_t w = {(bf16_t)acc[rs][nt][0], (bf16_t)acc[rs][nt][1], (bf16_t)acc[rs][nt][2],
+                              (bf16_t)acc[rs][nt][3]};
+                *(bf16x4_t*)(ob + 16 * nt) = w;
+            }
         }
     }
 }
@@ -487,39 +518,42 @@ __device__ __forceinline__ void mha_bwd_dkv_body(AttBwdLds<DK>& sm, int kblk, in
 #pragma unroll
             for (int i = 0; i < NP; ++i) rd[i] = att_stage_rowdot<DK>(stO, yb, ldo, i0 + AM_ROWS, Tq, tid, i);
         }
-        // s[it][r] = q(i0 + 16 it + 4 g + r) . k(kj); dp likewise with dout . v
-        f32x4_t s[4], dp[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            s[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            dp[it] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sQ[cur], 16 * it, ks, lane), kf[ks],
-                                                                s[it], 0, 0, 0);
-                dp[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sO[cur], 16 * it, ks, lane), vf[ks],
-                                                                 dp[it], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float4 l4 = *(const float4*)&sL[cur][16 * it + 4 * g];
-            const float4 d4 = *(const float4*)&sD[cur][16 * it + 4 * g];
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = i0 + 16 * it + 4 * g + r;
-                const float sv = s[it][r] * scale + ((kmask || (CAUSAL && kj > qi + causal - 1)) ? -1e9f : 0.f);
-                const float p = __expf(sv - lv[r]);
-                s[it][r] = p;
-                dp[it][r] = p * (dp[it][r] - dl[r]) * scale;    // dS
-            }
-        }
-        // dv^T[d][key] += sum_query dout[query][d] p[query][key]; dk^T likewise with q and dS
+        // s[it][r] = q(i0 + 16 it + 4 g + r) . k(kj); dp likewise with dout . v -- 32 streamed rows at a
+        // time (two 16-row tiles: the contraction of one step of the second pair of products)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8_t pf = att_pack(s[2 * kk], s[2 * kk + 1]);
-            const bf16x8_t dsf = att_pack(dp[2 * kk], dp[2 * kk + 1]);
+            f32x4_t s[2], dp[2];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int it = 2 * kk + h2;
+                s[h2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                dp[h2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    s[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sQ[cur], 16 * it, ks, lane), kf[ks],
+                                                                    s[h2], 0, 0, 0);
+                    dp[h2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_frag_rows<DK>(sO[cur], 16 * it, ks, lane), vf[ks],
+                                                                     dp[h2], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int it = 2 * kk + h2;
+                const float4 l4 = *(const float4*)&sL[cur][16 * it + 4 * g];
+                const float4 d4 = *(const float4*)&sD[cur][16 * it + 4 * g];
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = i0 + 16 * it + 4 * g + r;
+                    const float sv = s[h2][r] * scale + ((kmask || (CAUSAL && kj > qi + causal - 1)) ? -1e9f : 0.f);
+                    const float p = __expf(sv - lv[r]);
+                    s[h2][r] = p;
+                    dp[h2][r] = p * (dp[h2][r] - dl[r]) * scale;    // dS
+                }
+            }
+            // dv^T[d][key] += sum_query dout[query][d] p[query][key]; dk^T likewise with q and dS
+            const bf16x8_t pf = att_pack(s[0], s[1]);
+            const bf16x8_t dsf = att_pack(dp[0], dp[1]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 av[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -552,26 +586,29 @@ __device__ __forceinline__ void mha_bwd_dkv_body(AttBwdLds<DK>& sm, int kblk, in
 }
 
 // One launch for the whole backward pass of the attention: the workgroups of a head are its dK/dV
-// blocks (first: the longer role) and its dQ blocks, side by side on one XCD.
-template <int DK, bool CAUSAL>
-__global__ __launch_bounds__(256) void mha_bwd_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                           const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
-                                                           const uint8_t* __restrict__ key_mask, int causal, int h,
-                                                           int Tq, int Tk, float scale, const bf16_t* __restrict__ out,
-                                                           const bf16_t* __restrict__ dout, int ldo,
-                                                           const float* __restrict__ lse, float* __restrict__ delta,
-                                                           bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_,
-                                                           bf16_t* __restrict__ dv, int lddq, int lddk, int lddv,
-                                                           int heads, int only) {
+// blocks (first: the longer role) and its dQ blocks (64 * RS queries each), side by side on one XCD.
+// Three waves per SIMD for head sizes up to 64: at T = 250 the 4 + 2 workgroups of each of 128 heads
+// are then all on the chip at once (at two waves per SIMD the launch ran as two rounds).
+#ifndef AM_BWD_MIN_WGS
+#define AM_BWD_MIN_WGS 3
+#endif
+template <int DK, bool CAUSAL, int RS>
+__global__ __launch_bounds__(256, DK <= 64 ? AM_BWD_MIN_WGS : 1) void mha_bwd_mfma_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ldq, int ldk, int ldv,
+    const uint8_t* __restrict__ key_mask, int causal, int h, int Tq, int Tk, float scale,
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, int ldo, const float* __restrict__ lse,
+    float* __restrict__ delta, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk_, bf16_t* __restrict__ dv, int lddq,
+    int lddk, int lddv, int heads, int only) {
     __shared__ __attribute__((aligned(16))) AttBwdLds<DK> sm;
     // (``only``: 1 = the dK/dV blocks alone, 2 = the dQ blocks alone -- for measurements)
-    const int nkb = only == 2 ? 0 : (Tk + AM_ROWS - 1) / AM_ROWS, nqb = only == 1 ? 0 : (Tq + AM_ROWS - 1) / AM_ROWS;
+    const int nkb = only == 2 ? 0 : (Tk + AM_ROWS - 1) / AM_ROWS;
+    const int nqb = only == 1 ? 0 : (Tq + AM_ROWS * RS - 1) / (AM_ROWS * RS);
     int w, head;
     if (!att_xcd_map(nkb + nqb, heads, w, head)) return;
     if (w < nkb)
         mha_bwd_dkv_body<DK, CAUSAL>(sm, w, head, q, k, v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, out, dout,
                                      ldo, lse, dk_, dv, lddk, lddv);
     else
-        mha_bwd_dq_body<DK, CAUSAL>(sm, w - nkb, head, q, k, v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale, out,
-                                    dout, ldo, lse, delta, dq, lddq);
+        mha_bwd_dq_body<DK, CAUSAL, RS>(sm, w - nkb, head, q, k, v, ldq, ldk, ldv, key_mask, causal, h, Tq, Tk, scale,
+                                        out, dout, ldo, lse, delta, dq, lddq);
 }
