@@ -49,7 +49,13 @@ __device__ __forceinline__ void gb_glds16(const bf16_t* src, uint32_t lds_addr) 
 }
 __device__ __forceinline__ void gb_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // all but the 8 youngest loads of this wave (two stages of four) have landed
-__device__ __forceinline__ void gb_wait_oldest_stage() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+// (a wave that fills one piece of the A image per stage instead of two has two stages of three)
+template <int LOADS>
+__device__ __forceinline__ void gb_wait_oldest_stage() {
+    static_assert(LOADS == 3 || LOADS == 4, "loads per wave and stage");
+    if constexpr (LOADS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
 
 // row image with 64-byte rows
 __device__ __forceinline__ int row32_img_off(int r, int chunk) { return (r * 4 + (chunk ^ (((r >> 2) & 1) << 1))) * 8; }
@@ -60,9 +66,15 @@ __device__ __forceinline__ bf16x8_t lds_frag_rows32(const bf16_t* img, int row, 
 // What the epilogue of the large-tile core supports: a plain store of alpha * acc (fp32 or bf16,
 // optional output-row scatter), per-column sum / sum of squares of the stored values (BatchNorm
 // statistics), raw split-K partial slabs, and the column sums of B taken on the matrix cores.
-template <class AMap, bool TA, bool TB>
-__device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const int bx, const int by, const int bz,
+//
+// MH: 16-row sets per wave, 8 for the 256-row tile; 4 makes a 128-row tile out of the same eight waves
+// (row images only: each wave then fills one piece of the A image per stage and the upper half of the
+// image's space stays unused).  ``bm``: first output row of the tile.
+template <class AMap, bool TA, bool TB, int MH = 8>
+__device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const int bm, const int by, const int bz,
                                               bf16_t* lds) {
+    static_assert(MH == 8 || (MH == 4 && !TA), "half tiles are built for row images of A only");
+    constexpr int NA = MH / 4;                        // pieces of the A image a wave fills per stage
     const int zb = p.zbatch > 1 ? (int)(bz / p.split_k) : 0;
     const int zsplit = p.zbatch > 1 ? (int)(bz % p.split_k) : (int)bz;
     const int seg_base = p.seg_base + zb;
@@ -74,15 +86,16 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int bm = bx * GB_BM, bn = by * GB_BN;
+    const int bn = by * GB_BN;
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
     const bf16_t* __restrict__ B = (const bf16_t*)p.B;
     const bf16_t* zero = (const bf16_t*)gb_zero_chunk;
     // LDS byte address of this wave's first piece of the A image of stage 0
     // LDS byte address of this wave's first piece of the A image of stage 0 (2 pieces of 1 KB per
     // wave, operand and stage)
-    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)lds + (uint32_t)wave * 2048u);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) bf16_t*)lds;
+    const uint32_t lds_wave_a = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)wave * (1024u * NA));
+    const uint32_t lds_wave_b = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)wave * 2048u);
 
     const int tiles_per_seg = (p.kseg + GB_BK - 1) / GB_BK;
     const int ntiles = p.nseg * tiles_per_seg;
@@ -90,9 +103,9 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
     const int t_begin = zsplit * per_split;
     const int t_end = min(ntiles, t_begin + per_split);
 
-    f32x4_t acc[8][4];
+    f32x4_t acc[MH][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MH; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -111,7 +124,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         const int q = wave * 2 + i;
         const int rchunk = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 8;
         if (!TA) {
-            const int r = 16 * q + (lane >> 2);
+            const int r = 16 * (wave * NA + (i < NA ? i : 0)) + (lane >> 2);
             arow[i] = p.amap.prep(min(bm + r, p.M - 1));
             acol[i] = rchunk;
             ak[i] = 0;
@@ -134,7 +147,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         }
     }
 
-    const bool want_bsum = !TB && p.epi.bsum != nullptr && bx == 0 && wm == 0;
+    const bool want_bsum = !TB && p.epi.bsum != nullptr && bm == 0 && wm == 0;
     f32x4_t bs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) bs[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -155,8 +168,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
     // every wave then has the same number of loads in flight at every step, and one counted wait
     // serves the whole loop.
     auto stage_tile = [&](int slot) {
-        const uint32_t dA = lds_wave + (uint32_t)slot * (2u * GB_STAGE_ELEMS);     // bytes
-        const uint32_t dB = dA + 2u * GB_A_ELEMS;
+        const uint32_t dA = lds_wave_a + (uint32_t)slot * (2u * GB_STAGE_ELEMS);     // bytes
+        const uint32_t dB = lds_wave_b + (uint32_t)slot * (2u * GB_STAGE_ELEMS) + 2u * GB_A_ELEMS;
         const bool live = ld_t < t_end;
         const int seg = live ? ld_seg : 0;
         const int k0 = ld_k0;
@@ -167,14 +180,14 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         if (!TA && seg != aoff_seg) {            // uniform: a new segment (convolution tap)
             aoff_seg = seg;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 const long o = p.amap.off(arow[i], seg_base + seg);
                 aok[i] = !AMap::kCanMiss || o >= 0;
                 aoff[i] = o + acol[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const bf16_t* src;
             if (!TA) {
                 src = (live && aok[i]) ? A + aoff[i] + k0 : zero;
@@ -199,7 +212,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         }
     };
     // A k-step is "request the twelve fragments from LDS" and "32 MFMAs on them".
-    bf16x8_t fa[8], fb[4];
+    bf16x8_t fa[MH], fb[4];
     auto read_frags = [&](int slot) {
         const bf16_t* sA = lds + slot * GB_STAGE_ELEMS;
         const bf16_t* sB = sA + GB_A_ELEMS;
@@ -210,14 +223,14 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
             fb[j] = TB ? lds_frag_rows32(sB, n0 + fr, fk) : lds_frag_tr<NC>(sB, n0, 0, lane);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m0 = wm * 128 + i * 16;
+        for (int i = 0; i < MH; ++i) {
+            const int m0 = wm * (16 * MH) + i * 16;
             fa[i] = TA ? lds_frag_tr<NC>(sA, m0, 0, lane) : lds_frag_rows32(sA, m0 + fr, fk);
         }
     };
     auto multiply = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MH; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -237,7 +250,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
         for (int s_ = 0; s_ < GB_NS - 1; ++s_) stage_tile(s_);
         int slot = 0;
         for (int t = t_begin; t < t_end; ++t) {
-            gb_wait_oldest_stage();          // this wave's loads of k-step t have landed ...
+            gb_wait_oldest_stage<NA + 2>();  // this wave's loads of k-step t have landed ...
             __syncthreads();                 // ... and everybody's; everybody is done reading k-step t-1
             if (late && t > t_begin) multiply();                // k-step t-1, fragments already in registers
             __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +280,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
             }
         }
     }
-    // element r of acc[i][j] is C[m = bm + wm*128 + i*16 + (lane & 15)][n = bn + wn*64 + j*16 + 4*(lane >> 4) + r]
+    // element r of acc[i][j] is C[m = bm + wm*16*MH + i*16 + (lane & 15)][n = bn + wn*64 + j*16 + 4*(lane >> 4) + r]
     float cs[4][4], cq[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -285,8 +298,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
             bias_v[j][r] = (e.bias && e.atomic != 2 && n < p.N) ? e.bias[n] : 0.f;
         }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = bm + wm * 128 + i * 16 + fr;
+    for (int i = 0; i < MH; ++i) {
+        const int m = bm + wm * (16 * MH) + i * 16 + fr;
         if (m >= p.M) continue;
         const int mo = out_row(p, m);
 #pragma unroll
@@ -358,7 +371,26 @@ __device__ __forceinline__ void gemm_big_body(const GemmProblem<AMap>& p, const 
 template <class AMap, bool TA, bool TB>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_kernel(GemmProblem<AMap> p) {
     __shared__ __attribute__((aligned(1024))) bf16_t lds[GB_LDS_ELEMS];
-    gemm_big_body<AMap, TA, TB>(p, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+    gemm_big_body<AMap, TA, TB>(p, blockIdx.x * GB_BM, blockIdx.y, blockIdx.z, lds);
+}
+
+// The same product with the last, partly filled round of workgroups cut into 128-row tiles: with T
+// tiles on 256 CUs the launch takes ceil(T / 256) tile times although the last round may hold few
+// tiles; its r tiles as 2 r half tiles (still one round when r <= 128) take little more than half a
+// tile time.  Workgroups 0 .. full - 1 are whole tiles in the order of the plain launch (x fastest),
+// the rest are the halves of tiles full, full + 1, ...
+template <class AMap>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_tail_kernel(GemmProblem<AMap> p, int tiles_m, int full) {
+    __shared__ __attribute__((aligned(1024))) bf16_t lds[GB_LDS_ELEMS];
+    const int id = blockIdx.x;
+    if (id < full) {
+        gemm_big_body<AMap, false, true>(p, (id % tiles_m) * GB_BM, id / tiles_m, 0, lds);
+    } else {
+        const int t = full + ((id - full) >> 1), half = (id - full) & 1;
+        const int bm = (t % tiles_m) * GB_BM + half * (GB_BM / 2);
+        if (bm >= p.M) return;
+        gemm_big_body<AMap, false, true, 4>(p, bm, t / tiles_m, 0, lds);
+    }
 }
 
 // ------------------------------------------------------------------ a table of weight gradients
@@ -416,7 +448,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_table_kernel(const GbI
     p.epi.c_dtype = ATHENA_F32;
     p.epi.atomic = 0;
     p.epi.alpha = 1.f;
-    gemm_big_body<PlainRows, true, false>(p, local % it.tiles_m, local / it.tiles_m, 0, lds);
+    gemm_big_body<PlainRows, true, false>(p, (local % it.tiles_m) * GB_BM, local / it.tiles_m, 0, lds);
 }
 
 // does the large-tile core cover this problem?
@@ -453,10 +485,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_big_multi_kernel(const GbM
     const int local = blockIdx.x - m.first_tile[i];
     // a uniform switch instead of m.p[i]: every problem is addressed with constant offsets
     switch (i) {
-        case 0: { const int tm = (m.p[0].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[0], local % tm, local / tm, 0, lds); } break;
-        case 1: { const int tm = (m.p[1].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[1], local % tm, local / tm, 0, lds); } break;
-        case 2: { const int tm = (m.p[2].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[2], local % tm, local / tm, 0, lds); } break;
-        default: { const int tm = (m.p[3].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[3], local % tm, local / tm, 0, lds); } break;
+        case 0: { const int tm = (m.p[0].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[0], (local % tm) * GB_BM, local / tm, 0, lds); } break;
+        case 1: { const int tm = (m.p[1].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[1], (local % tm) * GB_BM, local / tm, 0, lds); } break;
+        case 2: { const int tm = (m.p[2].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[2], (local % tm) * GB_BM, local / tm, 0, lds); } break;
+        default: { const int tm = (m.p[3].M + GB_BM - 1) / GB_BM; gemm_big_body<AMap, TA, TB>(m.p[3], (local % tm) * GB_BM, local / tm, 0, lds); } break;
     }
 }
 
@@ -487,11 +519,25 @@ static int launch_gemm_big_multi(const GemmProblem<AMap>* probs, int count, hipS
     return ATHENA_OK;
 }
 
+#define GB_CHIP_TILES 256     // workgroups of this core the chip runs at a time (one per CU)
+static inline bool gb_half_tiles_enabled() {
+    static const bool on = !(getenv("ATHENA_GEMM_HALF_TILES") && atoi(getenv("ATHENA_GEMM_HALF_TILES")) == 0);
+    return on;
+}
 template <class AMap>
 static int launch_gemm_big(const GemmProblem<AMap>& p, bool ta, bool tb, hipStream_t stream) {
     const int tm = (p.M + GB_BM - 1) / GB_BM, tn = (p.N + GB_BN - 1) / GB_BN;
     const int gz = p.split_k * (p.zbatch > 1 ? p.zbatch : 1);
     const dim3 grid(tm, tn, gz);
+    // a last round of at most 128 tiles runs as half tiles (see gemm_big_tail_kernel)
+    const long tiles = (long)tm * tn;
+    const int last = (int)(tiles % GB_CHIP_TILES);
+    if (!ta && tb && gz == 1 && tiles > GB_CHIP_TILES && last > 0 && last <= GB_CHIP_TILES / 2 && gb_half_tiles_enabled()) {
+        const int full = (int)(tiles - last);
+        ATHENA_LAUNCH((gemm_big_tail_kernel<AMap>), dim3((unsigned)(full + 2 * last)), dim3(GB_THREADS), 0, stream, p, tm, full);
+        ATHENA_CHECK_LAUNCH("gemm(large tile, halved last round)");
+        return ATHENA_OK;
+    }
     if (!ta && tb) ATHENA_LAUNCH((gemm_big_kernel<AMap, false, true>), grid, dim3(GB_THREADS), 0, stream, p);
     else if (ta && !tb) ATHENA_LAUNCH((gemm_big_kernel<AMap, true, false>), grid, dim3(GB_THREADS), 0, stream, p);
     else return ATHENA_E_UNSUPPORTED;

@@ -38,6 +38,26 @@ def test_gemm_layouts(ops, cd, ta, tb, M, N, K):
     assert_close(C, ref, 2e-5 if cd == torch.float32 else 1e-5, "gemm")   # products of rounded inputs are exact in fp32 acc
 
 
+@pytest.mark.parametrize("M,N", [(4420, 3700), (4500, 3590), (1030, 27000)])
+def test_gemm_large_tiles_with_a_halved_last_round(ops, M, N):
+    """Plain bf16 products big enough for the 256 x 256 core whose tile count leaves a last round of at
+    most half a chip: those tiles run as 128-row halves (a half that starts beyond the last row
+    included).  Against the fp64 product of the rounded operands, with a bias, fp32 and bf16 outputs."""
+    K = 256
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64)
+    Bm = torch.randn(N, K, generator=g, dtype=torch.float64)
+    bias = torch.randn(N, generator=g, dtype=torch.float64)
+    ref = rounded(A, torch.bfloat16) @ rounded(Bm, torch.bfloat16).t() + bias
+    a, b = to_cd(A, torch.bfloat16), to_cd(Bm, torch.bfloat16)
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())
+    ops.gemm(a, b, C, M, N, K, trans_b=True, bias=bias.float().to(dev()))
+    assert_close(C, ref, 1e-5, "fp32 output")
+    C16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, b, C16, M, N, K, trans_b=True, bias=bias.float().to(dev()))
+    assert_close(C16, ref, 5e-3, "bf16 output")
+
+
 @pytest.mark.parametrize("cd", DTYPES)
 def test_gemm_epilogues(ops, cd):
     M, N, K = 150, 88, 64
