@@ -293,54 +293,204 @@ __global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t*
     }
 }
 
-// One workgroup per row v of the table: the tokens are scanned 64 per wave, their matches noted as
-// ballot words in LDS, and every thread then walks the matches in token order and sums its
-// columns.  Every row of dE is written (zero where no token has the id), the order of the sum is
-// fixed, and no atomics are needed.
-#define EMB_SEG 8192          // tokens per pass over the ballot words
-template <typename T>
+// One WAVE per row v of the table (four rows per workgroup): the wave walks the tokens 256 at a time --
+// four coalesced loads of ids in flight, a compare and a ballot each -- and where a chunk holds
+// matches (a wave-uniform branch) adds those tokens' rows of dy into the columns its lanes own, 64
+// apart.  Matches are taken in token order, so the sum has a fixed order, but their rows are fetched
+// four at a time with every load in bounds and unconditional (a token or column that does not exist
+// reads a neighbour and counts with factor zero): a row that many tokens point at -- the padding id,
+// sos -- costs an issue slot per match and element, not a memory round trip.  Every row of dE is
+// written (zero where no token has the id); no LDS, no barriers, no atomics.
+// EMB_COLS: columns per lane and pass over the tokens (4: tables up to 256 wide in one pass; 8: 512 per pass)
+template <typename T, int EMB_COLS>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
                                                         int ntok, int d, int V, float xscale, uint32_t thresh,
                                                         float dscale, const uint64_t* rng_state, uint32_t site,
                                                         float* __restrict__ dtable) {
-    __shared__ uint64_t hit[EMB_SEG / 64];
-    const int v = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
     uint64_t key = 0;
     if (thresh) key = rng_key(rng_state, site);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int c0 = 0; c0 < d; c0 += 256) {
-        const int c = c0 + threadIdx.x;
-        float acc = 0.f;
-        for (int t0 = 0; t0 < ntok; t0 += EMB_SEG) {
-            const int seg = min(EMB_SEG, ntok - t0);
-            __syncthreads();
-            for (int w = wave; w * 64 < seg; w += 4) {
-                const int t = t0 + w * 64 + lane;
-                bool m = false;
-                if (t < ntok) {
-                    int id = ids[t];
-                    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-                    m = id == v;
-                }
-                const uint64_t b = __ballot(m);
-                if (lane == 0) hit[w] = b;
+    for (int c0 = 0; c0 < d; c0 += 64 * EMB_COLS) {
+        float acc[EMB_COLS];
+        int col[EMB_COLS];
+        float cok[EMB_COLS];
+#pragma unroll
+        for (int k = 0; k < EMB_COLS; ++k) {
+            acc[k] = 0.f;
+            const int c = c0 + 64 * k + lane;
+            col[k] = c < d ? c : d - 1;
+            cok[k] = c < d ? xscale : 0.f;
+        }
+        for (int t0 = 0; t0 < ntok; t0 += 256) {
+            int idv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = t0 + 64 * q + lane;
+                idv[q] = ids[t < ntok ? t : ntok - 1];
             }
-            __syncthreads();
-            for (int w = 0; w * 64 < seg; ++w) {
-                uint64_t b = hit[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = t0 + 64 * q + lane;
+                int id = idv[q];
+                id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+                uint64_t b = __ballot(t < ntok && id == v);
                 while (b) {
-                    const int t = t0 + w * 64 + __builtin_ctzll(b);
-                    b &= b - 1;
-                    if (c < d) {
-                        const long i = (long)t * d + c;
-                        float g = to_f32<T>(dy[i]) * xscale;
-                        if (thresh) g *= dropout_mult(key, (uint64_t)i, thresh, dscale);
-                        acc += g;
+                    // up to four matches, rows fetched together, added in token order
+                    int tok[4];
+                    float w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool any = b != 0;
+                        tok[j] = any ? t0 + 64 * q + __builtin_ctzll(b) : (j ? tok[j - 1] : 0);
+                        w[j] = any ? 1.f : 0.f;
+                        b &= b - 1;
                     }
+                    float g[4][EMB_COLS];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < EMB_COLS; ++k) g[j][k] = to_f32<T>(dy[(long)tok[j] * d + col[k]]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < EMB_COLS; ++k) {
+                            float x = g[j][k] * (cok[k] * w[j]);
+                            if (thresh) x *= dropout_mult(key, (uint64_t)((long)tok[j] * d + col[k]), thresh, dscale);
+                            acc[k] += x;
+                        }
                 }
             }
         }
-        if (c < d) dtable[(long)v * d + c] = acc;
+#pragma unroll
+        for (int k = 0; k < EMB_COLS; ++k) {
+            const int c = c0 + 64 * k + lane;
+            if (c < d) dtable[(long)v * d + c] = acc[k];
+        }
+    }
+}
+
+// The same walk for tables whose width is a multiple of four (with dy aligned to four elements): a lane
+// owns FOUR CONSECUTIVE columns, so a token's row of 256 columns is one load per lane, one hash decides
+// its four dropout multipliers, and eight matches are in flight at a time.  A pass over the tokens
+// covers 256 columns.
+template <typename T>
+__device__ __forceinline__ void emb_load4(const T* p, float (&x)[4]);
+template <>
+__device__ __forceinline__ void emb_load4<float>(const float* p, float (&x)[4]) {
+    const float4 v = *(const float4*)p;
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void emb_load4<bf16_t>(const bf16_t* p, float (&x)[4]) {
+    const uint2 v = *(const uint2*)p;
+    x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xffff0000u);
+    x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+#define EMB_BATCH 8
+// adds the rows of dy of the tokens in [ta, tb) whose id is v into acc (columns cc .. cc + 3, factor cf)
+// -- unless there are more than ``limit`` of them: then false comes back as soon as that shows
+template <typename T>
+__device__ __forceinline__ bool emb_walk(const T* __restrict__ dy, const int32_t* __restrict__ ids, int ta, int tb, int d,
+                                         int V, int v, int cc, float cf, uint64_t key, uint32_t thresh, float dscale,
+                                         int lane, int limit, float (&acc)[4]) {
+    int count = 0;
+    for (int t0 = ta; t0 < tb; t0 += 256) {
+        int idv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + 64 * q + lane;
+            idv[q] = ids[t < tb ? t : tb - 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = t0 + 64 * q + lane;
+            int id = idv[q];
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+            uint64_t b = __ballot(t < tb && id == v);
+            count += __popcll(b);
+            if (count > limit) return false;
+            while (b) {
+                int tok[EMB_BATCH];
+                float w[EMB_BATCH];
+#pragma unroll
+                for (int j = 0; j < EMB_BATCH; ++j) {
+                    const bool any = b != 0;
+                    tok[j] = any ? t0 + 64 * q + __builtin_ctzll(b) : (j ? tok[j - 1] : ta);
+                    w[j] = any ? cf : 0.f;
+                    b &= b - 1;
+                }
+                float g[EMB_BATCH][4];
+#pragma unroll
+                for (int j = 0; j < EMB_BATCH; ++j) emb_load4<T>(dy + (long)tok[j] * d + cc, g[j]);
+#pragma unroll
+                for (int j = 0; j < EMB_BATCH; ++j) {
+                    float m[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (thresh) dropout_mult4(key, (uint64_t)((long)tok[j] * d + cc), thresh, dscale, m);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += g[j][r] * (w[j] * m[r]);
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// Sixteen rows of the table per workgroup, one per wave.  A wave sums the rows of dy of the tokens that
+// point at its row by itself, in token order -- up to EMB_HOT of them.  A row more tokens point at (the
+// padding id, sos) would keep one wave busy for a microsecond per eight tokens while the rest of the
+// chip has finished, so the wave gives up when the count passes EMB_HOT and the sixteen waves take such
+// a row together afterwards: each sums a sixteenth of the tokens (contiguous, in order) and the
+// sixteen partial sums are added in wave order.  Either way the order of the additions depends on
+// the ids alone.
+#define EMB_HOT 48
+template <typename T>
+__global__ __launch_bounds__(1024) void embed_bwd_vec_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
+                                                             int ntok, int d, int V, float xscale, uint32_t thresh,
+                                                             float dscale, const uint64_t* rng_state, uint32_t site,
+                                                             float* __restrict__ dtable) {
+    __shared__ float part[16][256];
+    __shared__ int hot[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int v = blockIdx.x * 16 + wave;
+    uint64_t key = 0;
+    if (thresh) key = rng_key(rng_state, site);
+    int slice = (ntok + 15) / 16;
+    slice = (slice + 63) & ~63;
+    for (int c0 = 0; c0 < d; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        const int cc = c < d ? c : d - 4;               // a lane beyond the table reads its last columns, factor 0
+        const float cf = c < d ? xscale : 0.f;
+        bool done = true;
+        if (v < V) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            done = emb_walk<T>(dy, ids, 0, ntok, d, V, v, cc, cf, key, thresh, dscale, lane, EMB_HOT, acc);
+            if (done && c < d) *(float4*)(dtable + (long)v * d + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        if (lane == 0) hot[wave] = done ? 0 : 1;
+        __syncthreads();
+        for (int r = 0; r < 16; ++r) {
+            if (!hot[r]) continue;                       // uniform over the workgroup
+            const int vr = blockIdx.x * 16 + r;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const int ta = wave * slice, tb = min(ntok, ta + slice);
+            if (ta < tb) emb_walk<T>(dy, ids, ta, tb, d, V, vr, cc, cf, key, thresh, dscale, lane, 0x7fffffff, acc);
+            *(float4*)&part[wave][4 * lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (wave == 0 && c < d) {
+                float4 t = *(const float4*)&part[0][4 * lane];
+#pragma unroll
+                for (int w = 1; w < 16; ++w) {
+                    const float4 u = *(const float4*)&part[w][4 * lane];
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                *(float4*)(dtable + (long)vr * d + c) = t;
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                 // hot[] is rewritten by the next pass
     }
 }
 
@@ -370,17 +520,22 @@ extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L
                                 float* dtable, athena_stream_t stream) {
     ATHENA_REQUIRE(dy && ids && dtable && B > 0 && L > 0 && d > 0 && V > 0, ATHENA_E_SHAPE, "athena_embed_bwd: bad arguments");
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f), ATHENA_E_SHAPE, "athena_embed_bwd: dropout args");
-    ATHENA_REQUIRE((long)B * L < (1L << 31) - EMB_SEG, ATHENA_E_SHAPE, "athena_embed_bwd: too many tokens");
+    ATHENA_REQUIRE((long)B * L < (1L << 31) - 64, ATHENA_E_SHAPE, "athena_embed_bwd: too many tokens");
     const int ntok = B * L;
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == ATHENA_BF16)
-        ATHENA_LAUNCH(embed_bwd_kernel<bf16_t>, dim3((unsigned)V), dim3(256), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
-    else if (dtype == ATHENA_F32)
-        ATHENA_LAUNCH(embed_bwd_kernel<float>, dim3((unsigned)V), dim3(256), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
-    else
+    const dim3 grid((unsigned)((V + 3) / 4)), grid16((unsigned)((V + 15) / 16));
+    const bool vec = d % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dtable & 15) == 0;
+    if (dtype == ATHENA_BF16) {
+        if (vec) ATHENA_LAUNCH(embed_bwd_vec_kernel<bf16_t>, grid16, dim3(1024), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        else ATHENA_LAUNCH((embed_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+    } else if (dtype == ATHENA_F32) {
+        if (vec) ATHENA_LAUNCH(embed_bwd_vec_kernel<float>, grid16, dim3(1024), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        else ATHENA_LAUNCH((embed_bwd_kernel<float, 8>), grid, dim3(256), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+    } else {
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_bwd: dtype");
+    }
     ATHENA_CHECK_LAUNCH("athena_embed_bwd");
     return ATHENA_OK;
 }

@@ -653,12 +653,14 @@ def test_embedding_and_pe(ops, cd):
     assert_close(dx, rounded(dy, cd) * ((yr > 0) & (yr < 6)).double(), 1e-6, "relu6 gate")
 
 
-def test_embedding_grad_many_tokens_with_dropout(ops):
-    """More tokens than one pass over the match words holds, ids outside the table (clamped like the
-    forward pass clamps them), a width that is no multiple of the workgroup, and the dropout
-    decisions of the forward pass: grad = sum over tokens of dy * (y / (table * xs + pe)), i.e. the
-    multiplier each element of the forward output shows.  Two runs agree bit for bit."""
-    B, L, d, V = 5, 1800, 320, 37
+@pytest.mark.parametrize("d,V", [(320, 37), (600, 10), (38, 9), (530, 5)])
+def test_embedding_grad_many_tokens_with_dropout(ops, d, V):
+    """Thousands of tokens, ids outside the table (clamped like the forward pass clamps them), widths
+    that are no multiple of a wave's 64 columns and wider than one pass over the tokens covers, a
+    row count that does not fill the last workgroup, and the dropout decisions of the forward pass:
+    grad = sum over tokens of dy * (y / (table * xs + pe)), i.e. the multiplier each element of the
+    forward output shows.  Two runs agree bit for bit."""
+    B, L = 5, 1800
     g = torch.Generator().manual_seed(11)
     ids = torch.randint(-2, V + 2, (B, L), generator=g).to(torch.int32)
     table = (torch.rand(V, d, generator=g) + 1.0)
