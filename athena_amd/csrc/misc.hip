@@ -396,12 +396,20 @@ __device__ __forceinline__ bool emb_walk(const T* __restrict__ dy, const int32_t
                                          int V, int v, int cc, float cf, uint64_t key, uint32_t thresh, float dscale,
                                          int lane, int limit, float (&acc)[4]) {
     int count = 0;
+    // the ids of the next 256 tokens are requested before the current ones are looked at
+    int nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = ta + 64 * q + lane;
+        nxt[q] = ids[t < tb ? t : tb - 1];
+    }
     for (int t0 = ta; t0 < tb; t0 += 256) {
         int idv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int t = t0 + 64 * q + lane;
-            idv[q] = ids[t < tb ? t : tb - 1];
+            idv[q] = nxt[q];
+            const int t = t0 + 256 + 64 * q + lane;
+            nxt[q] = ids[t < tb ? t : tb - 1];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -437,27 +445,27 @@ __device__ __forceinline__ bool emb_walk(const T* __restrict__ dy, const int32_t
     return true;
 }
 
-// Sixteen rows of the table per workgroup, one per wave.  A wave sums the rows of dy of the tokens that
+// NW rows of the table per workgroup, one per wave.  A wave sums the rows of dy of the tokens that
 // point at its row by itself, in token order -- up to EMB_HOT of them.  A row more tokens point at (the
 // padding id, sos) would keep one wave busy for a microsecond per eight tokens while the rest of the
-// chip has finished, so the wave gives up when the count passes EMB_HOT and the sixteen waves take such
-// a row together afterwards: each sums a sixteenth of the tokens (contiguous, in order) and the
-// sixteen partial sums are added in wave order.  Either way the order of the additions depends on
+// chip has finished, so the wave gives up when the count passes EMB_HOT and the NW waves take such
+// a row together afterwards: each sums an NW-th of the tokens (contiguous, in order) and the
+// partial sums are added in wave order.  Either way the order of the additions depends on
 // the ids alone.
 #define EMB_HOT 48
-template <typename T>
-__global__ __launch_bounds__(1024) void embed_bwd_vec_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void embed_bwd_vec_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
                                                              int ntok, int d, int V, float xscale, uint32_t thresh,
                                                              float dscale, const uint64_t* rng_state, uint32_t site,
                                                              float* __restrict__ dtable) {
-    __shared__ float part[16][256];
-    __shared__ int hot[16];
+    __shared__ float part[NW][256];
+    __shared__ int hot[NW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int v = blockIdx.x * 16 + wave;
+    const int v = blockIdx.x * NW + wave;
     uint64_t key = 0;
     if (thresh) key = rng_key(rng_state, site);
-    int slice = (ntok + 15) / 16;
+    int slice = (ntok + NW - 1) / NW;
     slice = (slice + 63) & ~63;
     for (int c0 = 0; c0 < d; c0 += 256) {
         const int c = c0 + 4 * lane;
@@ -471,9 +479,9 @@ __global__ __launch_bounds__(1024) void embed_bwd_vec_kernel(const T* __restrict
         }
         if (lane == 0) hot[wave] = done ? 0 : 1;
         __syncthreads();
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < NW; ++r) {
             if (!hot[r]) continue;                       // uniform over the workgroup
-            const int vr = blockIdx.x * 16 + r;
+            const int vr = blockIdx.x * NW + r;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const int ta = wave * slice, tb = min(ntok, ta + slice);
             if (ta < tb) emb_walk<T>(dy, ids, ta, tb, d, V, vr, cc, cf, key, thresh, dscale, lane, 0x7fffffff, acc);
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(1024) void embed_bwd_vec_kernel(const T* __restrict
             if (wave == 0 && c < d) {
                 float4 t = *(const float4*)&part[0][4 * lane];
 #pragma unroll
-                for (int w = 1; w < 16; ++w) {
+                for (int w = 1; w < NW; ++w) {
                     const float4 u = *(const float4*)&part[w][4 * lane];
                     t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
                 }
@@ -515,6 +523,13 @@ extern "C" int athena_embed_fwd(const float* table, const int32_t* ids, const fl
     return ATHENA_OK;
 }
 
+#define EMB_WAVES 4      // measured: 10 / 15 / 14 us at 4 / 8 / 16 waves on the benchmark shape, 32 / 28 / 26 us with half of the tokens on one id
+#define EMB_VEC(T)                                                                                                     \
+    do {                                                                                                               \
+        if (nw == 4) ATHENA_LAUNCH((embed_bwd_vec_kernel<T, 4>), gridw, dim3(256), 0, s, (const T*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);        \
+        else if (nw == 8) ATHENA_LAUNCH((embed_bwd_vec_kernel<T, 8>), gridw, dim3(512), 0, s, (const T*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);   \
+        else ATHENA_LAUNCH((embed_bwd_vec_kernel<T, 16>), gridw, dim3(1024), 0, s, (const T*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);              \
+    } while (0)
 extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L, int d, int V, int dtype,
                                 float xscale, float drop_p, const uint64_t* rng_state, uint32_t rng_site,
                                 float* dtable, athena_stream_t stream) {
@@ -525,13 +540,15 @@ extern "C" int athena_embed_bwd(const void* dy, const int32_t* ids, int B, int L
     uint32_t th = drop_p > 0.f ? dropout_threshold(drop_p) : 0u;
     float ds = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)((V + 3) / 4)), grid16((unsigned)((V + 15) / 16));
+    static const int nw_env = getenv("ATHENA_EMBED_WAVES") ? atoi(getenv("ATHENA_EMBED_WAVES")) : 0;
+    const int nw = (nw_env == 4 || nw_env == 8 || nw_env == 16) ? nw_env : EMB_WAVES;
+    const dim3 grid((unsigned)((V + 3) / 4)), gridw((unsigned)((V + nw - 1) / nw));
     const bool vec = d % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dtable & 15) == 0;
     if (dtype == ATHENA_BF16) {
-        if (vec) ATHENA_LAUNCH(embed_bwd_vec_kernel<bf16_t>, grid16, dim3(1024), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        if (vec) EMB_VEC(bf16_t);
         else ATHENA_LAUNCH((embed_bwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, (const bf16_t*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     } else if (dtype == ATHENA_F32) {
-        if (vec) ATHENA_LAUNCH(embed_bwd_vec_kernel<float>, grid16, dim3(1024), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
+        if (vec) EMB_VEC(float);
         else ATHENA_LAUNCH((embed_bwd_kernel<float, 8>), grid, dim3(256), 0, s, (const float*)dy, ids, ntok, d, V, xscale, th, ds, rng_state, rng_site, dtable);
     } else {
         ATHENA_REQUIRE(false, ATHENA_E_UNSUPPORTED, "athena_embed_bwd: dtype");
