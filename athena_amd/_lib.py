@@ -62,6 +62,7 @@ class LayerTailFwd(Structure):
         ("z1", c_void_p), ("y1", c_void_p), ("mean1", c_void_p), ("rstd1", c_void_p), ("hpre", c_void_p),
         ("h", c_void_p), ("z2", c_void_p), ("y2", c_void_p), ("mean2", c_void_p), ("rstd2", c_void_p),
         ("next_w_t", c_void_p * 3), ("next_b", c_void_p * 3), ("next_out", c_void_p * 3),
+        ("x_f32", c_void_p), ("y_out_f32", c_void_p),
     ]
 
 

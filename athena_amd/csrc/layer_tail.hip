@@ -375,6 +375,12 @@ struct LtFwd {
     const bf16_t* wn[3];
     const float* bn[3];
     bf16_t* on[3];
+    // optional: the residual input once more in fp32 (read instead of x for the residual sum; x stays the
+    // operand nothing here multiplies), and an fp32 copy of the launch's final LayerNorm output for
+    // the launch that takes it as ITS residual input -- the stream then passes from layer to layer
+    // unrounded, and only the copies that products read are bf16
+    const float* x32;
+    float* y32;
 };
 
 template <bool FFN, bool QKV, int RB>
@@ -405,7 +411,23 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     // ---- everything small first: these are the last loads that are waited for as a group
     LtTile<RB> tc, tx;
     lt_tile_load<RB>(tc, p.ctx, LT_D, 0, row0, p.rows, tid);
-    lt_tile_load<RB>(tx, p.x, LT_D, 0, row0, p.rows, tid);
+    // the residual input: its fp32 copy straight into the accumulator layout if there is one, else the
+    // bf16 tile through LDS
+    const bool wide = p.x32 != nullptr;
+    float res[RB][2][4];
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = min(row0 + 16 * i + fr, p.rows - 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 t = *(const float4*)(p.x32 + (long)row * LT_D + n0 + 16 * j + 4 * fq);
+                res[i][j][0] = t.x; res[i][j][1] = t.y; res[i][j][2] = t.z; res[i][j][3] = t.w;
+            }
+        }
+    } else {
+        lt_tile_load<RB>(tx, p.x, LT_D, 0, row0, p.rows, tid);
+    }
     const bool hi = tid >= LT_D;
     const int ve = tid & (LT_D - 1);
     float vv[3], bv[LT_MAX_DFF / LT_THREADS];
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     if (FFN) lt_load_unit(ub, lt_unit_ptr(p.w1, LT_D, n0, 0, lane), LT_D);
     __builtin_amdgcn_sched_barrier(0);
     lt_tile_to_img<RB>(img_a, tc, tid);
-    lt_tile_to_img<RB>(st0, tx, tid);
+    if (!wide) lt_tile_to_img<RB>(st0, tx, tid);
     vecs[hi][ve] = vv[0];
     vecs[2 + hi][ve] = vv[1];
     vecs[4 + hi][ve] = vv[2];
@@ -447,15 +469,16 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     __syncthreads();
     LT_STAMP(1);
 
-    float res[RB][2][4];                                         // the residual input, in accumulator layout
+    if (!wide) {                                                 // the residual input, in accumulator layout
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bf16x4_t t = lt_img_get4<RB>(st0, 16 * i + fr, n0 + 16 * j + 4 * fq);
+            for (int j = 0; j < 2; ++j) {
+                const bf16x4_t t = lt_img_get4<RB>(st0, 16 * i + fr, n0 + 16 * j + 4 * fq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) res[i][j][r] = (float)t[r];
-        }
+                for (int r = 0; r < 4; ++r) res[i][j][r] = (float)t[r];
+            }
+    }
     f32x4_t acc[RB][2];
     float v[RB][2][4];
     lt_zero<RB>(acc);
@@ -476,6 +499,17 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     // z1 -> st1 (st0 may still be read for x by slower waves), y1 -> img_y
     lt_add_ln<RB>(v, res, vecs[0], vecs[1], vecs[2], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean1,
               p.rstd1, red, FFN ? st1 : st0, img_y);
+    if (!FFN && p.y32) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = row0 + 16 * i + fr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (row < p.rows)
+                    *(float4*)(p.y32 + (long)row * LT_D + n0 + 16 * j + 4 * fq) =
+                        make_float4(v[i][j][0], v[i][j][1], v[i][j][2], v[i][j][3]);
+        }
+    }
     __syncthreads();                                         // z1 and y1 images complete; img_a free again
     LT_STAMP(3);
     lt_img_to_global<RB>(FFN ? st1 : st0, p.z1, LT_D, 0, row0, p.rows, tid);
@@ -563,6 +597,17 @@ __global__ __launch_bounds__(LT_THREADS) void layer_tail_fwd_kernel(const LtFwd 
     lt_add_ln<RB>(f, v, vecs[3], vecs[4], vecs[5], p.eps, p.thresh, p.dscale, key, row0, p.rows, wave, lane, p.mean2,
               p.rstd2, red, zimg, yimg);
     LT_STAMP(5);
+    if (p.y32) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = row0 + 16 * i + fr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (row < p.rows)
+                    *(float4*)(p.y32 + (long)row * LT_D + n0 + 16 * j + 4 * fq) =
+                        make_float4(f[i][j][0], f[i][j][1], f[i][j][2], f[i][j][3]);
+        }
+    }
     __syncthreads();
     lt_img_to_global<RB>(zimg, p.z2, LT_D, 0, row0, p.rows, tid);
     lt_img_to_global<RB>(yimg, p.y2, LT_D, 0, row0, p.rows, tid);
@@ -951,6 +996,10 @@ extern "C" int athena_layer_tail_fwd(const athena_layer_tail_fwd_desc* d, athena
     p.z1 = (bf16_t*)d->z1; p.y1 = (bf16_t*)d->y1; p.mean1 = d->mean1; p.rstd1 = d->rstd1;
     p.hpre = (bf16_t*)d->hpre; p.h = (bf16_t*)d->h;
     p.z2 = (bf16_t*)d->z2; p.y2 = (bf16_t*)d->y2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
+    ATHENA_REQUIRE(lt_al16(d->x_f32) && lt_al16(d->y_out_f32), ATHENA_E_SHAPE,
+                   "athena_layer_tail_fwd: the fp32 residual buffers must be 16-byte aligned");
+    p.x32 = d->x_f32;
+    p.y32 = d->y_out_f32;
     const bool qkv = d->next_w_t[0] != nullptr;
     for (int m = 0; m < 3; ++m) {
         ATHENA_REQUIRE(!qkv || (m > 0 && d->dff == 0) ||

@@ -344,10 +344,18 @@ class EncoderLayerFn(torch.autograd.Function):
                     all(m.tiled_t is not None for m in (nxt.self_attn.wq, nxt.self_attn.wk, nxt.self_attn.wv)) and \
                     os.environ.get("ATHENA_TAIL_QKV", "1") != "0":
                 nq = (nxt.self_attn.wq, nxt.self_attn.wk, nxt.self_attn.wv)
+            # the residual stream passes from tail to tail in fp32 (the layer in front left a copy)
+            x32 = layer.__dict__.pop("_pre_x32", None)
+            if x32 is not None and (x32[0] != x2.data_ptr() or x32[1] != (M, d)):
+                x32 = None
+            keep32 = nxt is not None and os.environ.get("ATHENA_TAIL_FP32_STREAM", "1") != "0" and \
+                ops.layer_tail_ok(x2, d, nxt.self_attn.dense, nxt.ffn0, nxt.ffn1)
             t = ops.layer_tail_fwd(c, x2, layer.self_attn.dense, layer.norm1, layer.ffn0, layer.ffn1,
                                    layer.norm2, LN_EPS, p, rng, layer.site_res1, layer.site_ffn_h, layer.site_res2,
-                                   next_qkv=nq)
+                                   next_qkv=nq, x32=x32[2] if x32 is not None else None, want_y32=keep32)
             y2 = t.pop("y2")
+            if keep32:
+                nxt.__dict__["_pre_x32"] = (y2.data_ptr(), (M, d), t.pop("y32"))
             if nq is not None:
                 nxt.__dict__["_pre_qkv"] = (y2.data_ptr(), (M, d), (t.pop("q"), t.pop("k"), t.pop("v")))
             ctx.tail = t
@@ -456,9 +464,16 @@ class DecoderLayerFn(torch.autograd.Function):
             # the first tail also projects its output for the cross-attention's queries; the keys and
             # values of the memory may be waiting (the decoder stack projects them for all layers at once)
             fold = os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and layer.attn2.wq.tiled_t is not None
+            # (the residual stream passes from tail to tail in fp32, as in the encoder)
+            f32 = os.environ.get("ATHENA_TAIL_FP32_STREAM", "1") != "0"
+            x32 = layer.__dict__.pop("_pre_x32", None)
+            if x32 is not None and (x32[0] != t2.data_ptr() or x32[1] != (M, d)):
+                x32 = None
             ta = ops.layer_tail_fwd(c1, t2, layer.attn1.dense, layer.norm1, None, None, None, LN_EPS, p, rng,
-                                    layer.site_res1, 0, 0, next_qkv=(layer.attn2.wq,) if fold else None)
+                                    layer.site_res1, 0, 0, next_qkv=(layer.attn2.wq,) if fold else None,
+                                    x32=x32[2] if x32 is not None else None, want_y32=f32)
             y1 = ta["y1"]
+            y1_32 = ta.pop("y32", None)
             q2 = ta.pop("q", None)
             kv = layer.__dict__.pop("_pre_kv", None)
             if kv is not None and (kv[0] != m2.data_ptr() or kv[1] != (B * T, d)):
@@ -472,9 +487,13 @@ class DecoderLayerFn(torch.autograd.Function):
                     all(m.tiled_t is not None for m in (nxt.attn1.wq, nxt.attn1.wk, nxt.attn1.wv)) and \
                     os.environ.get("ATHENA_TAIL_QKV", "1") != "0":
                 nq = (nxt.attn1.wq, nxt.attn1.wk, nxt.attn1.wv)
+            keep32 = f32 and nxt is not None and ops.layer_tail_ok(t2, d, nxt.attn1.dense)
             tb = ops.layer_tail_fwd(c2, y1, layer.attn2.dense, layer.norm2, layer.ffn0, layer.ffn1, layer.norm3,
-                                    LN_EPS, p, rng, layer.site_res2, layer.site_ffn_h, layer.site_res3, next_qkv=nq)
+                                    LN_EPS, p, rng, layer.site_res2, layer.site_ffn_h, layer.site_res3, next_qkv=nq,
+                                    x32=y1_32, want_y32=keep32)
             y3 = tb.pop("y2")
+            if keep32:
+                nxt.__dict__["_pre_x32"] = (y3.data_ptr(), (M, d), tb.pop("y32"))
             if nq is not None:
                 nxt.__dict__["_pre_qkv"] = (y3.data_ptr(), (M, d), (tb.pop("q"), tb.pop("k"), tb.pop("v")))
             ctx.tails = (ta, tb)

@@ -102,6 +102,7 @@ class TransformerEncoder(nn.Module):
         store = getattr(self.layers[0], "store", None) if n else None
         for layer in self.layers:
             layer.__dict__.pop("_pre_qkv", None)          # nothing left over from a pass that did not finish
+            layer.__dict__.pop("_pre_x32", None)
             layer.__dict__.pop("_pending_dx", None)
         for i, layer in enumerate(self.layers):
             output = layer(output, src_mask=src_mask, training=training)
@@ -149,6 +150,7 @@ class TransformerDecoder(nn.Module):
         output = tgt
         for layer in self.layers:
             layer.__dict__.pop("_pre_qkv", None)
+            layer.__dict__.pop("_pre_x32", None)
             layer.__dict__.pop("_pending_dx", None)
             layer.__dict__.pop("_pre_kv", None)
         self._project_memory(memory)

@@ -194,10 +194,11 @@ def test_full_size_step_bf16(full_oracle):
     # tens of millions of logits (a six-sigma event of that noise) within the bound below (bf16 keeps 8
     # significant bits per GEMM operand through the layer stack)
     assert float(ea.pow(2).mean().sqrt()) <= 1e-2 and float(ec.pow(2).mean().sqrt()) <= 1e-2
-    # (AISHELL size, d_model 256: the one-launch layer tails keep the residual stream and the LayerNorms
-    # in fp32 -- measured 1.1e-2 / 1.4e-2; the d_model 512 recipes run their layers as separate launches
-    # that round the stream to bf16 between them -- measured 2.4e-2 / 3.0e-2 at a logit scale of 2.3)
-    bound = 2e-2 if o["name"] == "aishell" else max(3.5e-2, 1.5e-2 * scale)
+    # (d_model 256: the one-launch layer tails keep the residual stream and the LayerNorms in fp32, inside
+    # a launch and from launch to launch -- measured 5.8e-3 / 1.01e-2 at AISHELL size, 2.8e-3 / 7.4e-3 at the
+    # CTC-heavy one; the d_model 512 recipe runs its layers as separate launches that round the stream to
+    # bf16 between them -- measured 2.4e-2 / 3.1e-2 at a logit scale of 2.3)
+    bound = 1.2e-2 if o["name"] in ("aishell", "ctc_heavy") else max(3.5e-2, 1.5e-2 * scale)
     assert float(ea.max()) <= bound and float(ec.max()) <= bound
     loss, _ = model.get_loss((att, ctc), ds, training=True)
     assert abs(float(loss) - o["loss"]) <= 2e-3 * abs(o["loss"]), (float(loss), o["loss"])
