@@ -1192,6 +1192,47 @@ def test_layer_tail_matches_separate_kernels(ops, monkeypatch, tail_rows, dff, B
         assert rel_l2(g1[name], g0[name]) < 1.5e-2, (name, rel_l2(g1[name], g0[name]))
 
 
+@pytest.mark.parametrize("dff", [1024, 0])
+def test_layer_tail_fp32_residual_hand_over(ops, monkeypatch, tail_rows, dff):
+    """The fp32 copy of the residual stream that one tail leaves for the next (``y32`` / ``x32``): an fp32
+    copy that holds exactly the bf16 values changes nothing, bit for bit; the copy a launch leaves rounds
+    to the bf16 output it writes; and a residual input that differs from its bf16 rounding shows in the
+    output by about that difference (reference athena/layers/transformer.py:296-310 keeps the stream in
+    fp32 throughout).  With and without the feed-forward part, rows that do not fill the last block."""
+    from athena_amd.layers.commons import bind_all
+    from athena_amd.layers.transformer import TransformerEncoderLayer
+    from athena_amd.runtime import ParamStore
+    store = ParamStore(torch.bfloat16, device=dev())
+    layer = TransformerEncoderLayer(store, "enc", 256, 4, max(dff, 256), 0.1)
+    store.finalize(seed=3)
+    bind_all(layer)
+    store.refresh_shadows(force=True)
+    rows = 3 * 50 + 7
+    g = torch.Generator().manual_seed(8)
+    c = torch.randn(rows, 256, generator=g).to(dev()).to(torch.bfloat16)
+    x = (2.0 * torch.randn(rows, 256, generator=g)).to(dev())
+    xb = x.to(torch.bfloat16)
+    rng = torch.tensor([7, 1], dtype=torch.int64, device=dev())
+
+    def run(x32, want):
+        return ops.layer_tail_fwd(c, xb, layer.self_attn.dense, layer.norm1, layer.ffn0 if dff else None,
+                                  layer.ffn1 if dff else None, layer.norm2 if dff else None, 1e-8, 0.1, rng,
+                                  layer.site_res1, layer.site_ffn_h if dff else 0, layer.site_res2 if dff else 0,
+                                  x32=x32, want_y32=want)
+    last = "y2" if dff else "y1"
+    plain = run(None, True)
+    same = run(xb.float(), True)
+    for k in plain:
+        assert torch.equal(plain[k], same[k]), k
+    assert torch.equal(plain["y32"].to(torch.bfloat16), plain[last])
+    assert torch.isfinite(plain["y32"]).all()
+    wide = run(x, False)
+    # z1 = x + dropout(projection): the stored copy is the rounding of the sum with the unrounded x
+    diff = (wide["z1"].float() - plain["z1"].float()).abs().max()
+    assert 0 < float(diff) <= 2 * float((x - xb.float()).abs().max()) + 2 ** -6 * float(x.abs().max())
+    assert rel_l2(wide[last].float(), plain[last].float()) < 1e-2
+
+
 @pytest.mark.parametrize("dff,B,T", [(1024, 4, 64), (512, 2, 45)])
 def test_layer_tail_against_the_oracle_layer(ops, monkeypatch, tail_rows, dff, B, T):
     """The bf16 encoder layer with the one-launch tails (the benchmarked path) against
