@@ -112,6 +112,8 @@ _SIGNATURES = {
     "athena_colsum": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_add_layernorm_fwd": (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,
                                          _P, _P, _P, _P, _S]),
+    "athena_add_layernorm_fwd_wide": (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, c_int, c_float, _P, c_uint32,
+                                              _P, _P, _P, _P, _P, _S]),
     "athena_add_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P, c_uint32, c_int,
                                          _P, _P, _P, _P, _P, c_int64, _S]),
     "athena_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),

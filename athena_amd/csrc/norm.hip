@@ -171,14 +171,20 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __r
                                                                     float dscale, const uint64_t* rng_state,
                                                                     uint32_t site, T* __restrict__ z,
                                                                     T* __restrict__ y, float* __restrict__ mean,
-                                                                    float* __restrict__ rstd) {
+                                                                    float* __restrict__ rstd,
+                                                                    const float* __restrict__ a32,
+                                                                    float* __restrict__ y32) {
     const int rpb = 256 / G;                         // rows per block
     const int gl = threadIdx.x % G;
     const int row = blockIdx.x * rpb + threadIdx.x / G;
     const bool live = row < rows && gl * 8 < d;
     const long base = (long)(row < rows ? row : rows - 1) * d + (gl * 8 < d ? gl * 8 : 0);
+    // wide: the residual stream passes in fp32 -- a comes from its fp32 copy, statistics and y are
+    // worked out from the unrounded sum, and only the stored z and y are rounded
+    const bool wide = a32 != nullptr || y32 != nullptr;
     float v[8];
-    Vec8<T>::load(a + base, v);
+    if (a32) Vec8<float>::load(a32 + base, v);
+    else Vec8<T>::load(a + base, v);
     if (b) {
         float bv[8];
         Vec8<T>::load(b + base, bv);
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __r
     }
     // the stored z is what the backward pass reads; round-trip it so both passes see one value
     float s = 0.f;
+    if (live) Vec8<T>::store(z + base, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        v[i] = live ? to_f32<T>(from_f32<T>(v[i])) : 0.f;
+        v[i] = live ? (wide ? v[i] : to_f32<T>(from_f32<T>(v[i]))) : 0.f;
         s += v[i];
     }
-    if (live) Vec8<T>::store(z + base, v);
     const float mu = group_sum(s, G) / d;
     float q = 0.f;
 #pragma unroll
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_vec_kernel(const T* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (v[i] - mu) * rs * gm[i] + bt[i];
         Vec8<T>::store(y + base, o);
+        if (y32) Vec8<float>::store(y32 + base, o);
         if (gl == 0) {
             mean[row] = mu;
             rstd[row] = rs;
@@ -439,10 +446,34 @@ static inline bool ln_vec_ok(int d, std::initializer_list<const void*> ptrs) {
     return true;
 }
 
+static int add_layernorm_fwd_any(const void* a, const void* b, const float* gamma, const float* beta, float eps, int rows,
+                                 int d, int dtype, float drop_p, const uint64_t* rng_state, uint32_t rng_site, void* z,
+                                 void* y, float* mean, float* rstd, const float* a32, float* y32,
+                                 athena_stream_t stream);
+
 extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta,
                                         float eps, int rows, int d, int dtype, float drop_p,
                                         const uint64_t* rng_state, uint32_t rng_site, void* z, void* y,
                                         float* mean, float* rstd, athena_stream_t stream) {
+    return add_layernorm_fwd_any(a, b, gamma, beta, eps, rows, d, dtype, drop_p, rng_state, rng_site, z, y, mean, rstd,
+                                 nullptr, nullptr, stream);
+}
+
+extern "C" int athena_add_layernorm_fwd_wide(const void* a, const float* a_f32, const void* b, const float* gamma,
+                                             const float* beta, float eps, int rows, int d, int dtype, float drop_p,
+                                             const uint64_t* rng_state, uint32_t rng_site, void* z, void* y,
+                                             float* y_f32, float* mean, float* rstd, athena_stream_t stream) {
+    ATHENA_REQUIRE(a_f32 || y_f32, ATHENA_E_SHAPE, "add_layernorm_fwd_wide: neither fp32 buffer given");
+    ATHENA_REQUIRE((dtype == ATHENA_BF16 || dtype == ATHENA_F32) && ln_vec_ok(d, {a, b, gamma, beta, z, y, a_f32, y_f32}),
+                   ATHENA_E_UNSUPPORTED, "add_layernorm_fwd_wide: needs d %% 8 == 0, d <= 512 and 16-byte aligned operands");
+    return add_layernorm_fwd_any(a, b, gamma, beta, eps, rows, d, dtype, drop_p, rng_state, rng_site, z, y, mean, rstd,
+                                 a_f32, y_f32, stream);
+}
+
+static int add_layernorm_fwd_any(const void* a, const void* b, const float* gamma, const float* beta, float eps, int rows,
+                                 int d, int dtype, float drop_p, const uint64_t* rng_state, uint32_t rng_site, void* z,
+                                 void* y, float* mean, float* rstd, const float* a32, float* y32,
+                                 athena_stream_t stream) {
     ATHENA_REQUIRE(a && gamma && beta && z && y && mean && rstd, ATHENA_E_SHAPE, "add_layernorm_fwd: null operand");
     ATHENA_REQUIRE(rows > 0 && d > 0, ATHENA_E_SHAPE, "add_layernorm_fwd: bad shape rows=%d d=%d", rows, d);
     ATHENA_REQUIRE(drop_p == 0.f || (rng_state && drop_p < 1.f && b), ATHENA_E_SHAPE, "add_layernorm_fwd: dropout args");
@@ -454,14 +485,15 @@ extern "C" int athena_add_layernorm_fwd(const void* a, const void* b, const floa
         if (dtype == ATHENA_BF16)
             ATHENA_LAUNCH(add_layernorm_fwd_vec_kernel<bf16_t>, vgrid, dim3(256), 0, (hipStream_t)stream,
                                (const bf16_t*)a, (const bf16_t*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
-                               rng_site, (bf16_t*)z, (bf16_t*)y, mean, rstd);
+                               rng_site, (bf16_t*)z, (bf16_t*)y, mean, rstd, a32, y32);
         else
             ATHENA_LAUNCH(add_layernorm_fwd_vec_kernel<float>, vgrid, dim3(256), 0, (hipStream_t)stream,
                                (const float*)a, (const float*)b, gamma, beta, eps, rows, d, G, th, ds, rng_state,
-                               rng_site, (float*)z, (float*)y, mean, rstd);
+                               rng_site, (float*)z, (float*)y, mean, rstd, a32, y32);
         ATHENA_CHECK_LAUNCH("add_layernorm_fwd");
         return ATHENA_OK;
     }
+    ATHENA_REQUIRE(!a32 && !y32, ATHENA_E_UNSUPPORTED, "add_layernorm_fwd_wide: shape not covered");
     dim3 grid((rows + 3) / 4);
     if (dtype == ATHENA_BF16)
         ATHENA_LAUNCH(add_layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,

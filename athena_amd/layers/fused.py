@@ -362,11 +362,24 @@ class EncoderLayerFn(torch.autograd.Function):
             ctx.saved = (x2, s_att)
             return y2.view(B, T, d)
         a, s_att = mha_block_fwd(x2, x2, layer.self_attn, B, T, T, key_mask, layer.self_attn.band)
-        z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(x2, a, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
-                                                     layer.site_res1)
+        # (the residual stream passes from LayerNorm to LayerNorm in fp32 here too, where the kernels cover
+        # the width)
+        wide = ops.layernorm_wide_ok(a) and x2.is_contiguous() and \
+            os.environ.get("ATHENA_TAIL_FP32_STREAM", "1") != "0"
+        x32 = layer.__dict__.pop("_pre_x32", None)
+        if x32 is not None and (not wide or x32[0] != x2.data_ptr() or x32[1] != (M, d)):
+            x32 = None
+        r1 = ops.add_layernorm_fwd(x2, a, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng, layer.site_res1,
+                                   a32=x32[2] if x32 is not None else None, want_y32=wide)
+        z1, y1, mean1, rstd1 = r1[:4]
         f, s_ffn = ffn_fwd(y1, M, layer, p, rng)
-        z2, y2, mean2, rstd2 = ops.add_layernorm_fwd(y1, f, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng,
-                                                     layer.site_res2)
+        nxt = layer.__dict__.get("_next_in_stack")
+        keep32 = wide and bool(nxt)
+        r2 = ops.add_layernorm_fwd(y1, f, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng, layer.site_res2,
+                                   a32=r1[4] if wide else None, want_y32=keep32)
+        z2, y2, mean2, rstd2 = r2[:4]
+        if keep32:
+            nxt[0].__dict__["_pre_x32"] = (y2.data_ptr(), (M, d), r2[4])
         ctx.saved = (x2, s_att, z1, y1, mean1, rstd1, s_ffn, z2, mean2, rstd2)
         return y2.view(B, T, d)
 
@@ -500,14 +513,26 @@ class DecoderLayerFn(torch.autograd.Function):
             ctx.saved = (t2, m2, s1, s2)
             return y3.view(B, L, d)
         a1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True)
-        z1, y1, mean1, rstd1 = ops.add_layernorm_fwd(t2, a1, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng,
-                                                     layer.site_res1)
+        wide = ops.layernorm_wide_ok(a1) and t2.is_contiguous() and \
+            os.environ.get("ATHENA_TAIL_FP32_STREAM", "1") != "0"
+        x32 = layer.__dict__.pop("_pre_x32", None)
+        if x32 is not None and (not wide or x32[0] != t2.data_ptr() or x32[1] != (M, d)):
+            x32 = None
+        r1 = ops.add_layernorm_fwd(t2, a1, layer.norm1.gamma, layer.norm1.beta, LN_EPS, p, rng, layer.site_res1,
+                                   a32=x32[2] if x32 is not None else None, want_y32=wide)
+        z1, y1, mean1, rstd1 = r1[:4]
         a2, s2 = mha_block_fwd(y1, m2, layer.attn2, B, L, T, mem_key_mask, False)
-        z2, y2, mean2, rstd2 = ops.add_layernorm_fwd(y1, a2, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng,
-                                                     layer.site_res2)
+        r2 = ops.add_layernorm_fwd(y1, a2, layer.norm2.gamma, layer.norm2.beta, LN_EPS, p, rng, layer.site_res2,
+                                   a32=r1[4] if wide else None, want_y32=wide)
+        z2, y2, mean2, rstd2 = r2[:4]
         f, s_ffn = ffn_fwd(y2, M, layer, p, rng)
-        z3, y3, mean3, rstd3 = ops.add_layernorm_fwd(y2, f, layer.norm3.gamma, layer.norm3.beta, LN_EPS, p, rng,
-                                                     layer.site_res3)
+        nxt = layer.__dict__.get("_next_in_stack")
+        keep32 = wide and bool(nxt)
+        r3 = ops.add_layernorm_fwd(y2, f, layer.norm3.gamma, layer.norm3.beta, LN_EPS, p, rng, layer.site_res3,
+                                   a32=r2[4] if wide else None, want_y32=keep32)
+        z3, y3, mean3, rstd3 = r3[:4]
+        if keep32:
+            nxt[0].__dict__["_pre_x32"] = (y3.data_ptr(), (M, d), r3[4])
         ctx.saved = (t2, m2, s1, z1, y1, mean1, rstd1, s2, z2, y2, mean2, rstd2, s_ffn, z3, mean3, rstd3)
         return y3.view(B, L, d)
 

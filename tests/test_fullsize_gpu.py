@@ -196,9 +196,9 @@ def test_full_size_step_bf16(full_oracle):
     assert float(ea.pow(2).mean().sqrt()) <= 1e-2 and float(ec.pow(2).mean().sqrt()) <= 1e-2
     # (d_model 256: the one-launch layer tails keep the residual stream and the LayerNorms in fp32, inside
     # a launch and from launch to launch -- measured 5.8e-3 / 1.01e-2 at AISHELL size, 2.8e-3 / 7.4e-3 at the
-    # CTC-heavy one; the d_model 512 recipe runs its layers as separate launches that round the stream to
-    # bf16 between them -- measured 2.4e-2 / 3.1e-2 at a logit scale of 2.3)
-    bound = 1.2e-2 if o["name"] in ("aishell", "ctc_heavy") else max(3.5e-2, 1.5e-2 * scale)
+    # CTC-heavy one; the d_model 512 recipe runs its layers as separate launches whose LayerNorms hand the
+    # stream on in fp32 as well -- measured 7.6e-3 / 1.32e-2 at a logit scale of 2.3)
+    bound = 1.2e-2 if o["name"] in ("aishell", "ctc_heavy") else 1.8e-2
     assert float(ea.max()) <= bound and float(ec.max()) <= bound
     loss, _ = model.get_loss((att, ctc), ds, training=True)
     assert abs(float(loss) - o["loss"]) <= 2e-3 * abs(o["loss"]), (float(loss), o["loss"])

@@ -621,6 +621,48 @@ def test_batchnorm_relu6(ops, cd, rows, C):
     assert_close(dx, xr.grad, tol, "dx")
 
 
+@pytest.mark.parametrize("d", [64, 256, 512])
+def test_add_layernorm_with_the_stream_in_fp32(ops, d):
+    """athena_add_layernorm_fwd_wide: an fp32 copy of ``a`` that holds the bf16 values and no dropout gives the
+    plain call's z bit for bit and its y up to the rounding of z inside the statistics; with an
+    unrounded ``a32`` the result follows the fp64 LayerNorm of a32 + b (reference
+    athena/layers/transformer.py:305,308) more closely than the bf16 call does; the fp32 copy of y
+    rounds to y."""
+    rows = 37
+    g = torch.Generator().manual_seed(d)
+    a = (3.0 * torch.randn(rows, d, generator=g, dtype=torch.float64))
+    b = torch.randn(rows, d, generator=g, dtype=torch.float64)
+    gam = 1.0 + 0.2 * torch.randn(d, generator=g)
+    bet = 0.1 * torch.randn(d, generator=g)
+    a16, b16 = to_cd(a, torch.bfloat16), to_cd(b, torch.bfloat16)
+    gd, bd = gam.to(dev()), bet.to(dev())
+    z0, y0, m0, r0 = ops.add_layernorm_fwd(a16, b16, gd, bd, 1e-8, 0.0, None, 0)
+    z1, y1, m1, r1, y1w = ops.add_layernorm_fwd(a16, b16, gd, bd, 1e-8, 0.0, None, 0, a32=a16.float(), want_y32=True)
+    assert torch.equal(z0, z1)
+    assert_close(y1, y0.float(), 1.2e-2, "y with statistics of the unrounded sum")
+    assert torch.equal(y1w.to(torch.bfloat16), y1)
+    z2, y2, m2, r2, y2w = ops.add_layernorm_fwd(a16, b16, gd, bd, 1e-8, 0.0, None, 0, a32=a.float().to(dev()),
+                                                want_y32=True)
+    zr = a + rounded(b, torch.bfloat16)
+    mu = zr.mean(-1, keepdim=True)
+    var = ((zr - mu) ** 2).mean(-1, keepdim=True)
+    yr = (zr - mu) / torch.sqrt(var + 1e-8) * gam.double() + bet.double()
+    assert_close(y2w, yr, 1e-5, "fp32 copy of y")
+    assert_close(m2, mu.view(-1), 1e-5, "mean")
+    err_wide = float((y2w.double().cpu() - yr).abs().max())
+    zb = rounded(a, torch.bfloat16) + rounded(b, torch.bfloat16)
+    err_bf16 = float((y0.double().cpu() - yr).abs().max())
+    assert err_wide < 0.05 * err_bf16, (err_wide, err_bf16)
+    # dropout decisions do not depend on the variant
+    rng = torch.tensor([5, 3], dtype=torch.int64, device=dev())
+    zd0 = ops.add_layernorm_fwd(a16, b16, gd, bd, 1e-8, 0.5, rng, 4)[0]
+    zd1 = ops.add_layernorm_fwd(a16, b16, gd, bd, 1e-8, 0.5, rng, 4, a32=a16.float())[0]
+    assert torch.equal(zd0, zd1)
+    with pytest.raises(RuntimeError):
+        ops.add_layernorm_fwd(to_cd(a[:, :d - 4], torch.bfloat16).contiguous(), None, gd[:d - 4].contiguous(),
+                              bd[:d - 4].contiguous(), 1e-8, 0.0, None, 0, want_y32=True)
+
+
 # ------------------------------------------------------------------------------------------ PE / embedding
 @pytest.mark.parametrize("cd", DTYPES)
 def test_embedding_and_pe(ops, cd):

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 # the key projection's bias only shifts every score of a query by the same amount
 ZERO_GRAD = (".wk.bias",)
 # stated tolerance for bf16 logits against the fp32 oracle (absolute)
-BF16_LOGIT_TOL = 3e-2
+BF16_LOGIT_TOL = 1.2e-2
 
 
 def build(case, precision, full_length=False):
@@ -303,12 +303,13 @@ def test_bf16_logits_close_to_fp32_oracle(case):
     ec = float((ctc.float().cpu() - ctc_ref.detach()).abs().max())
     print("bf16 logits: max abs error attention %.3e ctc %.3e (logit scale %.2f / %.2f)" %
           (ea, ec, float(att_ref.abs().max()), float(ctc_ref.abs().max())))
-    # stated tolerance for the single worst logit: 3e-2 absolute, or 1.2 % of the largest |logit| where the
-    # logits are larger (bf16 keeps 8 significant bits: a logit of 5 is stored to within 2e-2 at best);
+    # stated tolerance for the single worst logit: 1.2e-2 absolute, or 0.8 % of the largest |logit| where the
+    # logits are larger (bf16 keeps 8 significant bits: a logit of 5 is stored to within 2e-2 at best;
+    # measured 0.3 - 0.6 % with the residual stream passed in fp32 between the LayerNorms);
     # the root-mean-square error stays within 1e-2 absolute (0.4 % of the largest |logit| where that is more:
     # the 50-class TIMIT head has logits up to 5.4)
-    assert ea <= max(BF16_LOGIT_TOL, 1.2e-2 * float(att_ref.abs().max())), ea
-    assert ec <= max(BF16_LOGIT_TOL, 1.2e-2 * float(ctc_ref.abs().max())), ec
+    assert ea <= max(BF16_LOGIT_TOL, 8e-3 * float(att_ref.abs().max())), ea
+    assert ec <= max(BF16_LOGIT_TOL, 8e-3 * float(ctc_ref.abs().max())), ec
     rms_a = float((att.float().cpu() - att_ref.detach()).pow(2).mean().sqrt())
     rms_c = float((ctc.float().cpu() - ctc_ref.detach()).pow(2).mean().sqrt())
     assert rms_a <= max(1e-2, 4e-3 * float(att_ref.abs().max())), rms_a
