@@ -424,7 +424,12 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
                                                       float* __restrict__ nrm, double* __restrict__ emis,
                                                       int32_t* __restrict__ argmax,
                                                       int32_t* __restrict__ first, float gscale,
-                                                      TG* __restrict__ grad) {
+                                                      TG* __restrict__ grad, int lds_gather) {
+    // lds_gather (with a row held in registers): the row is also laid down in LDS (ld floats of dynamic
+    // shared memory) and the logits of the label columns are picked up there.  With a few dozen labels
+    // the gather from memory hides behind the reductions; with 200 of them on each of 16 000 rows it is
+    // three million scattered requests, which the memory system takes longer over than over the rows.
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     __shared__ float red[32];
     __shared__ int32_t labs[CTC_MAX_U];
     const int row = blockIdx.x;
@@ -456,22 +461,35 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
     if constexpr (sizeof(T) == 4) {
         if (in_regs) row_regs_load<NR>((const float*)lr, ldl, x);
     }
+    const bool from_lds = in_regs && lds_gather != 0;        // (uniform)
     // the emissions are requested behind the row, so they arrive during its reductions
     const int L = min(max(label_len[b], 0), U);
     const int Lp = Sp / 2;
     constexpr int EP = CTC_MAX_U / 256;
     float ev[EP];
+    int ec[EP];
 #pragma unroll
     for (int i = 0; i < EP; ++i) {
         const int u = threadIdx.x + 256 * i;
         ev[i] = 0.f;
+        ec[i] = blank;
         if (u < L) {
             int c = labels[(long)b * U + u];
             if (c < 0 || c >= V) c = blank;
-            ev[i] = to_f32<T>(lr[c]);
+            ec[i] = c;
+            if (!from_lds) ev[i] = to_f32<T>(lr[c]);
         }
     }
-    const float xb = to_f32<T>(lr[blank]);
+    float xb = from_lds ? 0.f : to_f32<T>(lr[blank]);
+    if constexpr (sizeof(T) == 4) {
+        if (from_lds) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int c = (i * 256 + threadIdx.x) * 4;
+                if (c < ldl) *(float4*)(rowbuf + c) = x[i];
+            }
+        }
+    }
     float m, sum, wfac = 0.f;
     int am = 0;
     if (in_regs) {
@@ -480,6 +498,13 @@ __global__ __launch_bounds__(256) void ctc_row_kernel(const T* __restrict__ logi
         row_max_sum_arg<T>(lr, V, m, sum, am, red);
     } else {
         row_max_sum<T>(lr, V, m, sum, red);
+    }
+    if (from_lds) {
+        // (the barrier inside the statistics stands between the stores above and these reads)
+        xb = rowbuf[blank];
+#pragma unroll
+        for (int i = 0; i < EP; ++i)
+            if (threadIdx.x + 256 * i < L) ev[i] = rowbuf[ec[i]];
     }
     const float l = m + __logf(sum);
     if (threadIdx.x == 0) {
@@ -1475,9 +1500,13 @@ template <typename T, typename TG>
 static void launch_ctc_forward(const T* logits, int ldl, const int32_t* labels, const int32_t* label_len,
                                const int32_t* logit_len, int B, int Tn, int V, int U, int blank, const CtcWorkspace& ws,
                                float* loss, int32_t* argmax, float gscale, TG* grad, hipStream_t s) {
+    // (label logits from an LDS copy of the row: fp32 rows that fit the registers, from 64 labels on)
+    static const int lg_env = getenv("ATHENA_CTC_LDS_GATHER") ? atoi(getenv("ATHENA_CTC_LDS_GATHER")) : -1;
+    const int lds_gather = (sizeof(T) == 4 && ldl <= CTC_ROW_REGS * 1024 && (lg_env < 0 ? U >= 64 : lg_env != 0)) ? 1 : 0;
+    const size_t row_lds = lds_gather ? sizeof(float) * (size_t)ldl : 0;
 #define CTC_ROW(G, NR)                                                                                         \
-    ATHENA_LAUNCH((ctc_row_kernel<T, TG, G, NR>), dim3(B * Tn), dim3(256), 0, s, logits, ldl, labels, label_len, \
-                       logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first, gscale, grad)
+    ATHENA_LAUNCH((ctc_row_kernel<T, TG, G, NR>), dim3(B * Tn), dim3(256), row_lds, s, logits, ldl, labels, label_len, \
+                       logit_len, Tn, V, U, blank, ws.Sp, ws.lse, ws.nrm, ws.emis, argmax, ws.first, gscale, grad, lds_gather)
     if (grad) {
         if (ldl <= 5 * 1024) CTC_ROW(true, 5);
         else CTC_ROW(true, CTC_ROW_REGS);
