@@ -45,3 +45,8 @@ w_b = f["W"].bfloat16().float()
 c_wb = h["mem"].reshape(-1, h["mem"].shape[-1]) @ w_b + f["b"]
 err(c_wb, f["ctc"][..., :V].reshape(-1, V), "the same with the head's weights rounded to bf16")
 err(h["att"], f["att"], "attention logits, bf16 mode vs fp32 mode")
+# what the rounding of the head's input alone costs: the fp32 mode's encoder output rounded to bf16, exact head
+c_hr = f["mem"].bfloat16().float().reshape(-1, f["mem"].shape[-1]) @ f["W"] + f["b"]
+err(c_hr, f["ctc"][..., :V].reshape(-1, V), "exact head on the fp32 mode's encoder output rounded to bf16")
+c_wr = f["mem"].reshape(-1, f["mem"].shape[-1]) @ w_b + f["b"]
+err(c_wr, f["ctc"][..., :V].reshape(-1, V), "fp32 encoder output, head's weights rounded to bf16")
