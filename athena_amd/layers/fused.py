@@ -189,11 +189,13 @@ def mha_block_fwd(q_in, kv_in, attn, B, Tq, Tk, key_mask, causal, project=True, 
 
 
 def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, dq_in, acc_q, dkv_in, acc_kv,
-                  dctx=None, hand_over=None):
+                  dctx=None, hand_over=None, dkv_out=None):
     """Writes parameter grads; adds/stores the input grads into dq_in / dkv_in (may be one tensor).
     With ``dctx`` (the gradient of the attention context) the output projection is the caller's.
     ``hand_over``: a callable that takes the self-attention's dq | dk | dv buffer and sees to the
-    product with the fused kernels itself (the input gradient is then short of it on return)."""
+    product with the fused kernels itself (the input gradient is then short of it on return).
+    ``dkv_out`` = (buffer [Mk, 2d] as a column block of a wider matrix, its leading dimension): the
+    cross-attention's dk | dv go there and the product for dkv_in is the caller's."""
     d, h = attn.d_model, attn.num_heads
     dk = d // h
     q, k, v, ctx, lse = saved
@@ -215,9 +217,11 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
     elif fused is not None:
         # cross-attention: dk | dv side by side for the gradient of the memory
         dq = torch.empty_like(q)
-        dkv = torch.empty((Mk, 2 * d), dtype=k.dtype, device=k.device)
+        if dkv_out is not None:
+            dkv, ld = dkv_out
+        else:
+            dkv, ld = torch.empty((Mk, 2 * d), dtype=k.dtype, device=k.device), 2 * d
         dk_, dv = dkv[:, :d], dkv[:, d:]
-        ld = 2 * d
     else:
         dq = torch.empty_like(q)
         dk_ = torch.empty_like(k)
@@ -238,8 +242,9 @@ def mha_block_bwd(dout, q_in, kv_in, attn, saved, B, Tq, Tk, key_mask, causal, d
             hand_over(dq)                       # cross-attention: the query side's product is the caller's
         else:
             lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
-        ops.gemm(dkv, fused[:, d:], dkv_in, Mk, d, 2 * d, trans_b=True, lda=2 * d, ldb=3 * d, ldc=d,
-                 accumulate=acc_kv)
+        if dkv_out is None:
+            ops.gemm(dkv, fused[:, d:], dkv_in, Mk, d, 2 * d, trans_b=True, lda=2 * d, ldb=3 * d, ldc=d,
+                     accumulate=acc_kv)
     else:
         lin_bwd_x(dq, Mq, attn.wq, d, out=dq_in, accumulate=acc_q)
         lin_bwd_x(dk_, Mk, attn.wk, d, out=dkv_in, accumulate=acc_kv)
@@ -511,6 +516,8 @@ class DecoderLayerFn(torch.autograd.Function):
                 nxt.__dict__["_pre_qkv"] = (y3.data_ptr(), (M, d), (tb.pop("q"), tb.pop("k"), tb.pop("v")))
             ctx.tails = (ta, tb)
             ctx.saved = (t2, m2, s1, s2)
+            if ctx.mem_slot is not None:
+                ctx.mem_slot["kv_fwd"] = ctx.mem_slot.get("kv_fwd", 0) + 1
             return y3.view(B, L, d)
         a1, s1 = mha_block_fwd(t2, t2, layer.attn1, B, L, L, tgt_key_mask, True)
         wide = ops.layernorm_wide_ok(a1) and t2.is_contiguous() and \
@@ -565,7 +572,23 @@ class DecoderLayerFn(torch.autograd.Function):
             lin_bwd_w(tb["y1"], dh, M, layer.ffn0, d, dff)
             lin_bwd_w(s2[3], da2, M, layer.attn2.dense, d, d)
             slot = ctx.mem_slot
-            if slot is None:
+            # All layers' dk | dv side by side in one buffer, and ONE product with the stacked key / value
+            # kernels when the last of them is in, instead of a product per layer added into the buffer
+            # (six launches of 8000 x 256 x 512 on the decoder's chain of small launches became one of
+            # 8000 x 256 x 3072).  Needs every decoder layer of the pass on this path.
+            stack = layer.__dict__.get("_kv_stack")
+            wide = layer.store.stack_view("decoder.memory_kv") if stack is not None and slot is not None and \
+                slot.get("kv_fwd", 0) == stack[1] and m2.dtype == torch.bfloat16 and \
+                os.environ.get("ATHENA_DEC_KV_STACK", "1") != "0" else None
+            dkv_out = None
+            if wide is not None:
+                Kall = stack[1] * 2 * d
+                if slot.get("dkv_all") is None:
+                    slot["dkv_all"] = torch.empty((B * T, Kall), dtype=m2.dtype, device=m2.device)
+                    slot["kv_left"] = stack[1]
+                dkv_out = (slot["dkv_all"][:, stack[0] * 2 * d:(stack[0] + 1) * 2 * d], Kall)
+                dmem, acc_mem = None, False
+            elif slot is None:
                 dmem, acc_mem = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device), False
             else:
                 acc_mem = slot["buf"] is not None
@@ -577,7 +600,17 @@ class DecoderLayerFn(torch.autograd.Function):
             held = []
             fold_q = os.environ.get("ATHENA_TAIL_QKV", "1") != "0" and layer.attn2.wq.tiled is not None
             mha_block_bwd(None, y1, m2, layer.attn2, s2, B, L, T, mem_key_mask, False, d_y1, True, dmem, acc_mem,
-                          dctx=dctx2, hand_over=held.append if fold_q else None)
+                          dctx=dctx2, hand_over=held.append if fold_q else None, dkv_out=dkv_out)
+            if wide is not None:
+                slot["kv_left"] -= 1
+                if slot["kv_left"] == 0:
+                    acc_mem = slot["buf"] is not None
+                    if not acc_mem:
+                        slot["buf"] = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
+                    ops.gemm(slot["dkv_all"], wide, slot["buf"], B * T, d, Kall, trans_b=True, lda=Kall, ldb=Kall,
+                             ldc=d, accumulate=acc_mem)
+                    slot["dkv_all"] = None
+                dmem = slot["buf"]
             if slot is not None and not _MemoryGrad.leave(slot):
                 dmem = None
             ra = ops.layer_tail_bwd(d_y1, ta, layer.attn1.dense, layer.norm1, None, None, None, p, rng,

@@ -124,6 +124,15 @@ class TransformerDecoder(nn.Module):
             if hasattr(a, "attn1") and hasattr(b, "attn1"):
                 a.__dict__["_next_in_stack"] = [b]
                 b.__dict__["_prev_in_stack"] = [a]
+        # the gradient of the memory through all layers' cross-attention key / value projections as one
+        # product: their kernels get one more bf16 copy, side by side
+        cross = [l for l in decoder_layers if hasattr(l, "attn2")]
+        if len(cross) > 1 and len({l.attn2.d_model for l in cross}) == 1 and cross[0].attn2.d_model % 8 == 0 and \
+                not cross[0].store.finalized:
+            cross[0].store.stack_shadows("decoder.memory_kv", [n for l in cross for n in
+                                                              (l.attn2.wk.vname + ".kernel", l.attn2.wv.vname + ".kernel")])
+            for i, l in enumerate(cross):
+                l.__dict__["_kv_stack"] = (i, len(cross))
 
     def _project_memory(self, memory):
         """The key / value projections of the memory for ALL layers' cross-attention as one grouped

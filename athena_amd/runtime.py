@@ -66,6 +66,8 @@ class ParamStore:
         self.cuts = []
         self._site = 0
         self.shadow_groups = []
+        self.shadow_stacks = []
+        self.stacks = {}
 
     # ---- registration (before finalize) -------------------------------------------------
     def register(self, name, shape, init, trainable=True, matrix=None, tiled=False):
@@ -89,6 +91,24 @@ class ParamStore:
         if self.finalized:
             raise RuntimeError("ParamStore: group_shadows after finalize")
         self.shadow_groups.append(list(names))
+
+    def stack_shadows(self, tag, names):
+        """One MORE row-major bf16 copy of several matrices [in, out_i] with equal ``in``, side by side as
+        one [in, sum out_i] matrix (``stack_view(tag)``), whatever shadow groups the members belong to:
+        the gradients of one input through several Dense layers -- the decoder layers' cross-attention
+        key / value projections of the memory -- are then ONE product with their output gradients laid
+        side by side."""
+        if self.finalized:
+            raise RuntimeError("ParamStore: stack_shadows after finalize")
+        self.shadow_stacks.append((tag, list(names)))
+
+    def stack_view(self, tag):
+        """The stacked copy [in, sum out_i] of ``stack_shadows(tag, ...)``, or None (fp32 mode, unknown tag)."""
+        st = self.stacks.get(tag)
+        if st is None or self.shadow is None:
+            return None
+        base, r, total_c = st
+        return self.shadow[base:base + r * total_c].view(r, total_c)
 
     def new_site(self):
         """A fresh dropout site id (distinct RNG stream per dropout layer)."""
@@ -163,6 +183,21 @@ class ParamStore:
                     soff += ops.roundup(2 * r * c, ALIGN)
                 table += [s.offset, r, c, s.sh_off, s.sh_ld, s.sht_off, s.sht_ld, s.tl_off, s.tlt_off]
                 prefix.append(prefix[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+            for tag, names in self.shadow_stacks:
+                members = [self.by_name[n] for n in names]
+                rr = members[0].matrix[0]
+                if any(m.matrix is None or m.matrix[0] != rr or m.matrix[1] % 8 or rr % 8 for m in members):
+                    raise ValueError("ParamStore: shadows %s cannot be stacked" % (names,))
+                total_c = sum(m.matrix[1] for m in members)
+                base = soff
+                soff += ops.roundup(rr * total_c, ALIGN)
+                col = 0
+                for m in members:
+                    # (an entry always writes a transposed copy too: the member's own, once more)
+                    table += [m.offset, rr, m.matrix[1], base + col, total_c, m.sht_off, m.sht_ld, -1, -1]
+                    prefix.append(prefix[-1] + ((rr + 31) // 32) * ((m.matrix[1] + 31) // 32))
+                    col += m.matrix[1]
+                self.stacks[tag] = (base, rr, total_c)
             self.shadow = torch.zeros(max(soff, 8), dtype=torch.bfloat16, device=dev)
             self.sh_table = torch.tensor(table, dtype=torch.int64, device=dev)
             self.sh_prefix = torch.tensor(prefix, dtype=torch.int64, device=dev)
