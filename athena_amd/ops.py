@@ -3,6 +3,7 @@
 torch is used here for device memory and streams only; every function below enqueues one or
 more kernels of ``libathena_hip.so`` on ``torch.cuda.current_stream()``.
 """
+import contextlib
 import ctypes
 import os
 
@@ -162,6 +163,66 @@ def gemm_grouped(problems):
     _lib.check(lib.athena_gemm_grouped(descs, len(problems), _stream()), "athena_gemm_grouped")
 
 
+class _StepTables:
+    """Device memory for the problem tables of a step that is being recorded, filled once.
+
+    A table built while a HIP graph is captured holds addresses of that graph's buffers, so it cannot be
+    built ahead of the capture; uploaded by a recorded copy it would be copied again at every replay
+    (a copy node costs about as much as a small kernel, and a data-parallel step builds eight tables).
+    ``begin`` (before the capture) sets aside a chunk of device memory and a pinned host image of it;
+    a table built during the capture is placed in the image and the recorded kernel is given the
+    address the table will have; ``end`` (after the capture, before the first replay) copies the image
+    over in one piece and returns what the recorded step has to keep alive: the chunk and every cached
+    table the capture used.  Outside ``begin`` / ``end`` tables are uploaded where they are built."""
+    BYTES = 1 << 20
+    enabled = os.environ.get("ATHENA_STEP_TABLES", "1") != "0"
+    active = None
+
+    @classmethod
+    def begin(cls, device):
+        if not cls.enabled or cls.active is not None:
+            return
+        cls.active = {"chunk": torch.empty(cls.BYTES, dtype=torch.uint8, device=device),
+                      "host": torch.empty(cls.BYTES, dtype=torch.uint8).pin_memory(), "cursor": 0, "kept": []}
+
+    @classmethod
+    def place(cls, raw, device):
+        a = cls.active
+        if a is None or not torch.cuda.is_current_stream_capturing() or a["chunk"].device != device:
+            return None
+        at = (a["cursor"] + 255) // 256 * 256
+        if at + len(raw) > cls.BYTES:
+            return None
+        a["host"][at:at + len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        a["cursor"] = at + len(raw)
+        return a["chunk"][at:at + len(raw)]
+
+    @classmethod
+    def keep(cls, obj):
+        if cls.active is not None:
+            cls.active["kept"].append(obj)
+
+    @classmethod
+    def end(cls):
+        a, cls.active = cls.active, None
+        if a is None:
+            return None
+        if a["cursor"]:
+            a["chunk"][:a["cursor"]].copy_(a["host"][:a["cursor"]])
+            torch.cuda.current_stream(a["chunk"].device).synchronize()
+        return a["kept"] + [a["chunk"]]
+
+
+@contextlib.contextmanager
+def step_tables(owner, device):
+    """Around the captures of one recorded step: see ``_StepTables``.  ``owner`` keeps the tables."""
+    _StepTables.begin(device)
+    try:
+        yield
+    finally:
+        owner._tables = _StepTables.end()
+
+
 class _WgradTables:
     """Device copies of the problem tables of ``gemm_wgrad_table``, by content.
 
@@ -175,6 +236,9 @@ class _WgradTables:
 
     @staticmethod
     def _upload(arr, device):
+        placed = _StepTables.place(bytes(arr), device)
+        if placed is not None:
+            return placed, None
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).pin_memory()
         dev_t = torch.empty(host.numel(), dtype=torch.uint8, device=device)
         dev_t.copy_(host, non_blocking=True)
@@ -218,6 +282,7 @@ class _WgradTables:
             dev_t, host = cls._upload(blob, device)
             hit = (dev_t, host, total.value, len(arr), work, dev_t[fold_at:] if folds is not None else None,
                    None, n_fold.value, blocks.value)
+        _StepTables.keep(hit)
         cls.cache[key] = hit                     # most recently used last
         while len(cls.cache) > cls.KEEP:
             del cls.cache[next(iter(cls.cache))]
@@ -302,6 +367,7 @@ class _LnFolds:
     to step, so it is built once per distinct sequence; a new one is uploaded from pinned memory
     with an asynchronous copy, which a HIP-graph capture can record."""
     ARENA_BYTES = 128 << 20
+    KEEP = 64
     state = {}
 
     @classmethod
@@ -341,14 +407,21 @@ class _LnFolds:
         if not items:
             return
         key = tuple(items)
-        table = st["tables"].get(key)
+        table = st["tables"].pop(key, None)
         if table is None:
             import struct
             raw = b"".join(struct.pack("<QQQii", *it) for it in items)
-            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
-            devt = torch.empty(len(raw), dtype=torch.uint8, device=torch.device("cuda", st["index"]))
-            devt.copy_(host, non_blocking=True)
-            table = st["tables"][key] = (devt, host)
+            device = torch.device("cuda", st["index"])
+            devt, host = _StepTables.place(raw, device), None
+            if devt is None:
+                host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+                devt = torch.empty(len(raw), dtype=torch.uint8, device=device)
+                devt.copy_(host, non_blocking=True)
+            table = (devt, host)
+        _StepTables.keep(table)
+        st["tables"][key] = table                # most recently used last
+        while len(st["tables"]) > cls.KEEP:
+            del st["tables"][next(iter(st["tables"]))]
         lib = _lib.load()
         with torch.cuda.device(st["index"]):
             _lib.check(lib.athena_ln_fold_batched(table[0].data_ptr(), len(items), max(it[4] for it in items),

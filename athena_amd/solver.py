@@ -253,15 +253,16 @@ class _GraphStep:
         # the recorded forward pass always starts by rebuilding the bf16 weight copies: whether the
         # host flag happens to be set while recording must not decide what every replay does
         solver.model.store.shadows_dirty = True
-        with _capture(self.graph, solver._graph_pool()):
-            self.loss, self.metrics = solver._forward_backward(self.inputs)
-            if not split:
-                solver._update(1.0)
         self.update_graph = None
-        if split:
-            self.update_graph = torch.cuda.CUDAGraph()
-            with _capture(self.update_graph, solver._graph_pool()):
-                solver._update(1.0 / solver.world_size)
+        with ops.step_tables(self, next(iter(self.inputs.values())).device):
+            with _capture(self.graph, solver._graph_pool()):
+                self.loss, self.metrics = solver._forward_backward(self.inputs)
+                if not split:
+                    solver._update(1.0)
+            if split:
+                self.update_graph = torch.cuda.CUDAGraph()
+                with _capture(self.update_graph, solver._graph_pool()):
+                    solver._update(1.0 / solver.world_size)
         # the deferred scorers queued while recording become templates
         self.templates = []
         for m, n in zip(metrics_objs, before):
@@ -403,14 +404,17 @@ class _OneGraphPipelinedStep:
         try:
             # each piece's weight-gradient table runs on the side stream, in front of the piece's exchange
             _WgradQueue.side = solver._side if side_tables else None
-            with _capture(self.graph, solver._graph_pool()), ops.bf16_grad_handover():
+            with ops.step_tables(self, grads.device), _capture(self.graph, solver._graph_pool()), \
+                    ops.bf16_grad_handover():
                 outputs = solver.model(self.inputs, training=True)
                 self.loss, self.metrics = solver.model.get_loss(outputs, self.inputs, training=True)
                 total = sum(list(self.loss.values())) if isinstance(self.loss, dict) else self.loss
                 cuts = dict(store.cuts)
                 enc_cuts = [t for t, _ in store.cuts if t.startswith("encoder.")]          # forward order
                 ranges = _piece_ranges(store, [int(t.split(".")[1]) for t in enc_cuts])
-                g_mem, g_y = torch.autograd.grad(total, [cuts["memory"], cuts["y_net"]], retain_graph=True)
+                one = ops.const_scalar(total.device, 1.0) if total.dim() == 0 and total.dtype == torch.float32 \
+                    else None                      # the root gradient: a constant, not a fill per step
+                g_mem, g_y = torch.autograd.grad(total, [cuts["memory"], cuts["y_net"]], one, retain_graph=True)
                 exchange(*ranges[0])
                 up, g_up = cuts["memory"], g_mem
                 for k, tag in enumerate(reversed(enc_cuts)):
