@@ -179,6 +179,7 @@ _SIGNATURES = {
     "athena_ce_loss_bwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_float, _P, _P, c_float, _P, c_int, _S]),
     "athena_group_sum": (c_int, [_P, c_int, c_int, c_float, _P, _S]),
     "athena_weighted_sum": (c_int, [_P, _P, c_int, _P, _S]),
+    "athena_panel_gemm": (c_int, [_P, c_long, c_int, c_int, _P, _P, _P, _P, _S]),
     "athena_argmax_rows": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_seq_errors": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_clip_adam_step": (c_int, [_P, _P, _P, _P, c_long, _P, c_int, _P, _P, POINTER(AdamCfg), _P, _S]),

@@ -31,7 +31,7 @@ static int big_min_k() {
 static bool big_tiles_enabled() { return big_tiles_mode() != 0; }
 static bool big_tiles_forced() { return big_tiles_mode() == 2; }
 
-extern "C" int athena_abi_version(void) { return 14; }
+extern "C" int athena_abi_version(void) { return 15; }
 
 // ---------------------------------------------------------------- per-kernel timing sessions
 // Between athena_timing_begin and athena_timing_end every launch of the library carries two events

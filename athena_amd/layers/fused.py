@@ -43,6 +43,15 @@ def lin_fwd(x, M, dense, act=ACT_NONE, want_pre=False, drop_p=0.0, rng=None, sit
 
 def lin_fwd_group(items):
     """y_i = x_i @ kernel_i + bias_i for several Dense layers at once (one grouped launch)."""
+    x0, M0 = items[0][0], items[0][1]
+    if ops.PANEL_ENABLED and x0.dtype == torch.bfloat16 and x0.is_contiguous() and x0.data_ptr() % 16 == 0 and \
+            len(items) <= ops.PANEL_MAX_BLOCKS and \
+            all(x.data_ptr() == x0.data_ptr() and x.shape == x0.shape and M == M0 and d.in_features == 256 and d.out_features == 256 and d.tiled_t is not None
+                for x, M, d in items):
+        # one input, 256 x 256 kernels with fragment-tiled copies: the rows stay in LDS for all of them
+        outs = [torch.empty((M0, 256), dtype=x0.dtype, device=x0.device) for _ in items]
+        ops.panel_gemm(x0.view(-1, 256), M0, [(d.tiled_t, d.bias, o, 256) for (_, _, d), o in zip(items, outs)])
+        return outs
     outs, problems = [], []
     for x, M, dense in items:
         K, N = dense.in_features, dense.out_features
@@ -72,6 +81,13 @@ def lin_bwd_x(dy, M, dense, lddy, out=None, accumulate=False, act=ACT_NONE, aux=
         # a plain product with few rows and a long contraction (the vocabulary projection of the
         # decoder: 1056 x 256 x 4240 is 17 workgroups) is left to split its contraction
         plain = act == ACT_NONE and aux is None and not accumulate and drop_p == 0.0
+        if plain and ops.PANEL_ENABLED and N == 256 and K % 256 == 0 and K // 256 <= ops.PANEL_MAX_BLOCKS and \
+                getattr(dense, "tiled", None) is not None and lddy % 8 == 0 and dy.data_ptr() % 16 == 0 and \
+                out.data_ptr() % 16 == 0 and M * K < 2 ** 31:
+            # 256 outputs, many inputs: dy's rows stay in LDS while the kernel's rows go by in groups of 256
+            ops.panel_gemm(dy.view(-1, lddy) if dy.dim() != 2 else dy, M,
+                           [(dense.tiled[65536 * c:], None, out.view(-1)[256 * c:], K) for c in range(K // 256)])
+            return out
         ops.gemm(dy, dense.shadow, out, M, K, kc, trans_b=True, lda=lddy, ldb=dense.shadow.shape[1], ldc=K,
                  act=act, aux=aux, ldaux=ldaux, accumulate=accumulate, drop_p=drop_p, rng_state=rng, rng_site=site,
                  split_k=0 if (plain and kc >= 2048) else 1)

@@ -35,7 +35,7 @@ class XNet(nn.Module):
         self.bn1 = BatchNormParams(store, "x_net.bn1", num_filters)
         self.conv2 = Conv3x3Params(store, "x_net.conv2", num_filters, num_filters, as_matrix=True)
         self.bn2 = BatchNormParams(store, "x_net.bn2", num_filters)
-        self.dense = Dense(store, "x_net.dense", f2 * num_filters, d_model)
+        self.dense = Dense(store, "x_net.dense", f2 * num_filters, d_model, tiled=d_model == 256)   # tiled copies: input gradient as one panel launch
         self.site_drop = store.new_site()
 
     def forward(self, x0, training=None):

@@ -1798,3 +1798,62 @@ def test_attention_weights_on_request(cd):
             t_next, w_r = om.decoder_layer(pr, "dec.%d" % i, t_r, kv, causal, fmask, {"num_heads": h, "rate": 0.0}, False)
             assert_close(ws[i], w_r, tol if cd == torch.float32 else 4e-2, "cross-attention weights of layer %d" % i)
             t_r = t_next
+
+
+@pytest.mark.parametrize("rows,nblock", [(1, 1), (37, 3), (1056, 12), (8005, 12), (2049, 20)])
+def test_panel_gemm_against_fp64(ops, rows, nblock):
+    """x[rows, 256] times a list of 256 x 256 kernels in one launch (``athena_panel_gemm``: the key / value
+    Dense layers of every decoder layer's cross-attention on the encoder output, reference
+    athena/layers/attention.py:150-152) against fp64 products of the bf16-rounded operands: 16- and 32-row
+    workgroups, a last block of rows that is not full, one block without bias, outputs side by side in
+    one buffer and an input that is a column slice of a wider tensor."""
+    from athena_amd.layers.commons import Dense, bind_all
+    from athena_amd.runtime import ParamStore
+    store = ParamStore(torch.bfloat16, device=dev())
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([Dense(store, "d%d" % i, 256, 256, None, tiled=True) for i in range(nblock)])
+    holder = Holder()
+    store.finalize(seed=5)
+    bind_all(holder)
+    g = torch.Generator().manual_seed(rows)
+    with torch.no_grad():
+        for m in holder.layers:
+            m.bias.copy_(torch.randn(256, generator=g).to(dev()))
+    store.refresh_shadows(force=True)
+    wide = torch.randn(rows, 320, generator=g).to(dev()).to(torch.bfloat16)
+    x = wide[:, 64:]
+    out = torch.full((rows, 256 * nblock + 8), 7.0, dtype=torch.bfloat16, device=dev())
+    blocks = [(m.tiled_t, m.bias if i != 1 else None, out[:, 256 * i:], out.stride(0)) for i, m in enumerate(holder.layers)]
+    ops.panel_gemm(x, rows, blocks)
+    torch.cuda.synchronize()
+    assert torch.all(out[:, 256 * nblock:] == 7.0)
+    x64 = x.double()
+    for i, m in enumerate(holder.layers):
+        want = x64 @ m.kernel.detach().to(torch.bfloat16).double()
+        if i != 1:
+            want = want + m.bias.detach().double()
+        got = out[:, 256 * i:256 * (i + 1)].double()
+        assert (got - want).abs().max() <= 2 ** -8 * want.abs().max() + 1e-6, i
+        assert rel_l2(got, want) < 4e-3, i
+
+
+def test_panel_gemm_as_dense_input_gradient(ops):
+    """dx[rows, 768] = dy[rows, 256] kernel^T of a Dense(768 -> 256) through ``athena_panel_gemm`` (blocks = the
+    kernel's rows in groups of 256, tiled copy with the kernel's rows as rows) against ``athena_gemm``."""
+    from athena_amd.layers.commons import Dense, bind_all
+    from athena_amd.runtime import ParamStore
+    store = ParamStore(torch.bfloat16, device=dev())
+    dense = Dense(store, "x", 768, 256, None, tiled=True)
+    store.finalize(seed=9)
+    bind_all(dense)
+    store.refresh_shadows(force=True)
+    rows = 4000 + 3
+    dy = torch.randn(rows, 256, generator=torch.Generator().manual_seed(2)).to(dev()).to(torch.bfloat16)
+    dx = torch.empty(rows, 768, dtype=torch.bfloat16, device=dev())
+    ops.panel_gemm(dy, rows, [(dense.tiled[65536 * c:], None, dx[:, 256 * c:], 768) for c in range(3)])
+    want = dy.double() @ dense.kernel.detach().to(torch.bfloat16).double().t()
+    assert (dx.double() - want).abs().max() <= 2 ** -8 * want.abs().max() + 1e-6
+    assert rel_l2(dx.double(), want) < 4e-3
