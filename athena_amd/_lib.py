@@ -180,6 +180,7 @@ _SIGNATURES = {
     "athena_group_sum": (c_int, [_P, c_int, c_int, c_float, _P, _S]),
     "athena_weighted_sum": (c_int, [_P, _P, c_int, _P, _S]),
     "athena_panel_gemm": (c_int, [_P, c_long, c_int, c_int, _P, _P, _P, _P, _S]),
+    "athena_panel_gemm_k": (c_int, [_P, c_long, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, c_long, _S]),
     "athena_argmax_rows": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _S]),
     "athena_seq_errors": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _S]),
     "athena_clip_adam_step": (c_int, [_P, _P, _P, _P, c_long, _P, c_int, _P, _P, POINTER(AdamCfg), _P, _S]),

@@ -147,3 +147,134 @@ extern "C" int athena_panel_gemm(const void* x, long ldx, int rows, int nblock, 
     ATHENA_CHECK_LAUNCH("athena_panel_gemm");
     return ATHENA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The other way round: a LONG contraction and 256 output columns,
+//   out[rows, 256] (+)= act( sum_c a[rows, 256 c .. 256 c + 255] W_c + bias ),
+// W_c the [256 x 256] pieces of the kernel along its contraction.  A tile kernel gets 63 x 2 tiles of
+// 128 x 128 out of 8000 x 256 -- half the chip -- or splits the contraction and adds the parts up in a
+// second launch.  Here a workgroup owns 32 (16) rows of the OUTPUT: the accumulators stay in registers
+// over the whole contraction, the rows' 256-wide pieces of a pass through two LDS images (the next
+// piece is requested before the current one is multiplied), the weights stream as above.  One barrier
+// per piece.
+struct PanelKArgs {
+    const bf16_t* a;
+    long lda;
+    int rows, nchunk, kcols;           // kcols: valid columns of a (a multiple of 8; the last piece may be short)
+    int act, accumulate;
+    const float* bias;
+    bf16_t* out;
+    long ldo;
+    const bf16_t* w[PG_MAX_BLOCKS];
+    long ldw[PG_MAX_BLOCKS];
+};
+
+// columns col0 .. col0 + 255 of rows row0 ..; 16-byte pieces at or past ``kcols`` are taken from the last
+// valid piece of the row instead (finite values that meet zero weights), rows past the end from the last row
+template <int RB>
+__device__ __forceinline__ void pk_tile_load(LtTile<RB>& t, const bf16_t* __restrict__ src, long ld, int col0, int kcols,
+                                             int row0, int rows, int tid) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        const int q = tid + u * LT_THREADS;
+        const int col = min(col0 + (q & 31) * 8, kcols - 8);
+        t.v[u] = *(const bf16x8_t*)(src + (long)min(row0 + (q >> 5), rows - 1) * ld + col);
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(LT_THREADS) void panel_k_kernel(const PanelKArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t img[2][LT_IMG(RB)];
+    __shared__ __attribute__((aligned(16))) float bias_s[LT_D];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int row0 = blockIdx.x * 16 * RB;
+    const int n0 = wave * 32;
+
+    LtUnit u;
+    lt_load_unit(u, lt_unit_ptr(p.w[0], p.ldw[0], n0, 0, lane), p.ldw[0]);
+    LtTile<RB> t;
+    pk_tile_load<RB>(t, p.a, p.lda, 0, p.kcols, row0, p.rows, tid);
+    if (tid < LT_D) bias_s[tid] = p.bias ? p.bias[tid] : 0.f;
+    lt_tile_to_img<RB>(img[0], t, tid);
+    __syncthreads();
+    f32x4_t acc[RB][2];
+    lt_zero<RB>(acc);
+    for (int c = 0; c < p.nchunk; ++c) {
+        // (past the last piece both requests repeat it: nobody waits for them, and no load sits behind a
+        // branch, which would make the compiler's count of outstanding loads depend on the path)
+        const int cn = c + 1 < p.nchunk ? c + 1 : c;
+        pk_tile_load<RB>(t, p.a, p.lda, 256 * cn, p.kcols, row0, p.rows, tid);
+        lt_mul_unit<true, RB>(acc, u, img[c & 1], lane, lt_unit_ptr(p.w[cn], p.ldw[cn], n0, 0, lane), p.ldw[cn]);
+        lt_tile_to_img<RB>(img[(c + 1) & 1], t, tid);
+        __syncthreads();
+    }
+    // results through an image nobody reads any more, then 16 bytes per lane along rows
+    bf16_t* const o = img[0];       // (every wave is past the last pass' barrier: both images are free)
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 16 * j + 4 * fq;
+            const float4 b4 = *(const float4*)(&bias_s[n]);
+            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+            if (p.act == ATHENA_ACT_RELU6)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 6.f);
+            lt_store4(o + lt_img_off<RB>(16 * i + fr, n), v);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        const int q = tid + s * LT_THREADS;
+        const int r = q >> 5;
+        if (row0 + r >= p.rows) continue;
+        bf16x8_t v = *(const bf16x8_t*)(o + lt_img_off<RB>(r, (q & 31) * 8));
+        bf16_t* const dst = p.out + (long)(row0 + r) * p.ldo + (q & 31) * 8;
+        if (p.accumulate) {
+            const bf16x8_t old = *(const bf16x8_t*)dst;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)old[e]);
+        }
+        *(bf16x8_t*)dst = v;
+    }
+}
+
+extern "C" int athena_panel_gemm_k(const void* a, long lda, int rows, int kcols, int nchunk, const void* const* w_tiled,
+                                   const long* ldw, const float* bias, int act, int accumulate, void* out, long ldo,
+                                   athena_stream_t stream) {
+    ATHENA_REQUIRE(a && w_tiled && ldw && out, ATHENA_E_SHAPE, "athena_panel_gemm_k: null operand");
+    ATHENA_REQUIRE(rows > 0 && nchunk > 0 && nchunk <= PG_MAX_BLOCKS && kcols >= 8 && kcols % 8 == 0 &&
+                       kcols > 256 * (nchunk - 1) && kcols <= 256 * nchunk,
+                   ATHENA_E_SHAPE, "athena_panel_gemm_k: rows=%d columns=%d pieces=%d (at most %d pieces, the last one not empty)",
+                   rows, kcols, nchunk, PG_MAX_BLOCKS);
+    ATHENA_REQUIRE(act == ATHENA_ACT_NONE || act == ATHENA_ACT_RELU6, ATHENA_E_UNSUPPORTED, "athena_panel_gemm_k: act %d", act);
+    ATHENA_REQUIRE(lda >= kcols && lda % 8 == 0 && ldo >= LT_D && ldo % 8 == 0 && pg_al16(a) && pg_al16(out) &&
+                       (bias == nullptr || pg_al16(bias)),
+                   ATHENA_E_ALIGN, "athena_panel_gemm_k: 16-byte aligned operands and rows expected");
+    ATHENA_REQUIRE((long)rows * lda < (1L << 31) && (long)rows * ldo < (1L << 31), ATHENA_E_SHAPE, "athena_panel_gemm_k: too large");
+    PanelKArgs p = {};
+    p.a = (const bf16_t*)a;
+    p.lda = lda;
+    p.rows = rows;
+    p.nchunk = nchunk;
+    p.kcols = kcols;
+    p.act = act;
+    p.accumulate = accumulate;
+    p.bias = bias;
+    p.out = (bf16_t*)out;
+    p.ldo = ldo;
+    for (int c = 0; c < nchunk; ++c) {
+        ATHENA_REQUIRE(w_tiled[c] && pg_al16(w_tiled[c]) && ldw[c] >= LT_D && ldw[c] % 32 == 0, ATHENA_E_ALIGN,
+                       "athena_panel_gemm_k: piece %d: 16-byte aligned tiled weights with a contraction length that is a "
+                       "multiple of 32 expected", c);
+        p.w[c] = (const bf16_t*)w_tiled[c];
+        p.ldw[c] = ldw[c];
+    }
+    const int rb = lt_row_blocks(rows);
+    const dim3 grid((unsigned)((rows + 16 * rb - 1) / (16 * rb)));
+    if (rb == 1) ATHENA_LAUNCH((panel_k_kernel<1>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    else ATHENA_LAUNCH((panel_k_kernel<2>), grid, dim3(LT_THREADS), 0, (hipStream_t)stream, p);
+    ATHENA_CHECK_LAUNCH("athena_panel_gemm_k");
+    return ATHENA_OK;
+}

@@ -32,6 +32,14 @@ def lin_fwd(x, M, dense, act=ACT_NONE, want_pre=False, drop_p=0.0, rng=None, sit
     ldc = ldc or N
     out = torch.empty((M, ldc), dtype=out_dtype or x.dtype, device=x.device)
     pre = torch.empty_like(out) if want_pre else None
+    if x.dtype == torch.bfloat16 and ops.PANEL_ENABLED and N == 256 and ldc == N and K % 256 == 0 and \
+            512 <= K <= 256 * ops.PANEL_MAX_BLOCKS and getattr(dense, "tiled_t", None) is not None and \
+            act in (ACT_NONE, ACT_RELU6) and not want_pre and drop_p == 0.0 and out.dtype == torch.bfloat16 and \
+            x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and M * x.stride(0) < 2 ** 31:
+        # 256 outputs, a long contraction: the output rows stay in registers over all of it
+        ops.panel_gemm_k(x, M, K, [(dense.tiled_t[(256 * c // 32) * 512:], K) for c in range(K // 256)], out, N,
+                         bias=dense.bias, act=act)
+        return out, None
     if x.dtype == torch.bfloat16:
         ops.gemm(x, dense.shadow_t, out, M, N, K, trans_b=True, lda=K, ldb=dense.shadow_t.shape[1], ldc=ldc,
                  bias=dense.bias, act=act, c_pre=pre, drop_p=drop_p, rng_state=rng, rng_site=site)
@@ -623,8 +631,15 @@ class DecoderLayerFn(torch.autograd.Function):
                     acc_mem = slot["buf"] is not None
                     if not acc_mem:
                         slot["buf"] = torch.empty((B * T, d), dtype=m2.dtype, device=m2.device)
-                    ops.gemm(slot["dkv_all"], wide, slot["buf"], B * T, d, Kall, trans_b=True, lda=Kall, ldb=Kall,
-                             ldc=d, accumulate=acc_mem)
+                    peers = layer.__dict__.get("_kv_peers")
+                    if ops.PANEL_ENABLED and d == 256 and peers is not None and len(peers) == stack[1] and \
+                            2 * len(peers) <= ops.PANEL_MAX_BLOCKS and \
+                            all(a.wk.tiled is not None and a.wv.tiled is not None for a in peers):
+                        ops.panel_gemm_k(slot["dkv_all"], B * T, Kall, [(w.tiled, d) for a in peers for w in (a.wk, a.wv)],
+                                         slot["buf"], d, accumulate=acc_mem)
+                    else:
+                        ops.gemm(slot["dkv_all"], wide, slot["buf"], B * T, d, Kall, trans_b=True, lda=Kall, ldb=Kall,
+                                 ldc=d, accumulate=acc_mem)
                     slot["dkv_all"] = None
                 dmem = slot["buf"]
             if slot is not None and not _MemoryGrad.leave(slot):

@@ -133,6 +133,7 @@ class TransformerDecoder(nn.Module):
                                                               (l.attn2.wk.vname + ".kernel", l.attn2.wv.vname + ".kernel")])
             for i, l in enumerate(cross):
                 l.__dict__["_kv_stack"] = (i, len(cross))
+                l.__dict__["_kv_peers"] = [c.attn2 for c in cross]      # in the order of the stack
 
     def _project_memory(self, memory):
         """The key / value projections of the memory for ALL layers' cross-attention as one grouped

@@ -1857,3 +1857,67 @@ def test_panel_gemm_as_dense_input_gradient(ops):
     want = dy.double() @ dense.kernel.detach().to(torch.bfloat16).double().t()
     assert (dx.double() - want).abs().max() <= 2 ** -8 * want.abs().max() + 1e-6
     assert rel_l2(dx.double(), want) < 4e-3
+
+
+@pytest.mark.parametrize("rows,nchunk,short,act,accumulate", [(37, 2, 0, 0, False), (1056, 12, 0, 1, False),
+                                                              (8005, 20, 0, 1, False), (2049, 3, 112, 0, True),
+                                                              (300, 17, 112, 0, False)])
+def test_panel_gemm_k_against_fp64(ops, rows, nchunk, short, act, accumulate):
+    """out[rows, 256] (+)= act(a[rows, K] kernel + bias) with the output rows resident over the whole
+    contraction (``athena_panel_gemm_k``: the x_net Dense, reference athena/models/speech_transformer.py:95)
+    against fp64 on the bf16-rounded operands: 16- and 32-row workgroups, relu6, accumulation onto a bf16
+    buffer, and an ``a`` whose last 256-column piece is short (the kernel rows it lacks are zero)."""
+    from athena_amd.layers.commons import Dense, bind_all
+    from athena_amd.runtime import ParamStore
+    from athena_amd._lib import ACT_NONE, ACT_RELU6
+    K = 256 * nchunk
+    store = ParamStore(torch.bfloat16, device=dev())
+    dense = Dense(store, "x", K, 256, None, tiled=True)
+    store.finalize(seed=4)
+    bind_all(dense)
+    g = torch.Generator().manual_seed(rows + nchunk)
+    kcols = K - short
+    with torch.no_grad():
+        dense.kernel.mul_(8.0)
+        dense.kernel[kcols:].zero_()
+        dense.bias.copy_(torch.randn(256, generator=g).to(dev()))
+    store.refresh_shadows(force=True)
+    a = torch.randn(rows, kcols, generator=g).to(dev()).to(torch.bfloat16)
+    base = torch.randn(rows, 256, generator=g).to(dev()).to(torch.bfloat16)
+    out = base.clone() if accumulate else torch.empty(rows, 256, dtype=torch.bfloat16, device=dev())
+    ops.panel_gemm_k(a, rows, kcols, [(dense.tiled_t[8 * c * 512:], K) for c in range(nchunk)], out, 256,
+                     bias=dense.bias, act=ACT_RELU6 if act else ACT_NONE, accumulate=accumulate)
+    want = a.double() @ dense.kernel.detach().to(torch.bfloat16).double()[:kcols] + dense.bias.detach().double()
+    if act:
+        want = want.clamp(0.0, 6.0)
+    if accumulate:
+        want = want + base.double()
+    assert torch.isfinite(out).all()
+    assert (out.double() - want).abs().max() <= 2 ** -7 * want.abs().max() + 1e-6
+    assert rel_l2(out.double(), want) < 5e-3
+
+
+def test_panel_gemm_k_with_a_matrix_per_piece(ops):
+    """The sum over several Dense layers of dy_l kernel_l^T (the gradient of the encoder output through all
+    decoder layers' key / value projections, backward of reference athena/layers/attention.py:151-152): one piece
+    per 256 x 256 kernel, its tiled copy with the kernel's rows as rows."""
+    from athena_amd.layers.commons import Dense, bind_all
+    from athena_amd.runtime import ParamStore
+    store = ParamStore(torch.bfloat16, device=dev())
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([Dense(store, "d%d" % i, 256, 256, None, tiled=True) for i in range(4)])
+    holder = Holder()
+    store.finalize(seed=6)
+    bind_all(holder)
+    store.refresh_shadows(force=True)
+    rows = 4100
+    dy = torch.randn(rows, 1024, generator=torch.Generator().manual_seed(3)).to(dev()).to(torch.bfloat16)
+    out = torch.empty(rows, 256, dtype=torch.bfloat16, device=dev())
+    ops.panel_gemm_k(dy, rows, 1024, [(m.tiled, 256) for m in holder.layers], out, 256)
+    want = sum(dy[:, 256 * i:256 * (i + 1)].double() @ m.kernel.detach().to(torch.bfloat16).double().t()
+               for i, m in enumerate(holder.layers))
+    assert (out.double() - want).abs().max() <= 2 ** -7 * want.abs().max() + 1e-6
+    assert rel_l2(out.double(), want) < 5e-3
