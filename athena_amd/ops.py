@@ -225,15 +225,18 @@ class _StepTables:
 
     @classmethod
     def begin(cls, device):
-        if not cls.enabled or cls.active is not None:
+        if cls.active is not None:
             return
-        cls.active = {"chunk": torch.empty(cls.BYTES, dtype=torch.uint8, device=device),
-                      "host": torch.empty(cls.BYTES, dtype=torch.uint8).pin_memory(), "cursor": 0, "kept": []}
+        # (switched off, a recorded step still keeps the tables it used -- device copy and pinned source of
+        # the recorded upload -- alive: the caches below drop their oldest entries)
+        cls.active = {"chunk": torch.empty(cls.BYTES, dtype=torch.uint8, device=device) if cls.enabled else None,
+                      "host": torch.empty(cls.BYTES, dtype=torch.uint8).pin_memory() if cls.enabled else None,
+                      "cursor": 0, "kept": []}
 
     @classmethod
     def place(cls, raw, device):
         a = cls.active
-        if a is None or not torch.cuda.is_current_stream_capturing() or a["chunk"].device != device:
+        if a is None or a["chunk"] is None or not torch.cuda.is_current_stream_capturing() or a["chunk"].device != device:
             return None
         at = (a["cursor"] + 255) // 256 * 256
         if at + len(raw) > cls.BYTES:
@@ -255,7 +258,7 @@ class _StepTables:
         if a["cursor"]:
             a["chunk"][:a["cursor"]].copy_(a["host"][:a["cursor"]])
             torch.cuda.current_stream(a["chunk"].device).synchronize()
-        return a["kept"] + [a["chunk"]]
+        return a["kept"] + [a["chunk"]]      # (not the pinned image: it has been copied)
 
 
 @contextlib.contextmanager
@@ -328,8 +331,12 @@ class _WgradTables:
             hit = (dev_t, host, total.value, len(arr), work, dev_t[fold_at:] if folds is not None else None,
                    None, n_fold.value, blocks.value)
         _StepTables.keep(hit)
+        if hit[1] is None:
+            return hit                           # lies in a recorded step's own chunk: lives and dies with that step
         cls.cache[key] = hit                     # most recently used last
-        while len(cls.cache) > cls.KEEP:
+        # (nothing is dropped while a stream is recording: that would release pinned and device memory in the
+        # middle of a capture)
+        while len(cls.cache) > cls.KEEP and not torch.cuda.is_current_stream_capturing():
             del cls.cache[next(iter(cls.cache))]
         return hit
 
@@ -412,7 +419,6 @@ class _LnFolds:
     to step, so it is built once per distinct sequence; a new one is uploaded from pinned memory
     with an asynchronous copy, which a HIP-graph capture can record."""
     ARENA_BYTES = 128 << 20
-    KEEP = 64
     state = {}
 
     @classmethod
@@ -452,7 +458,7 @@ class _LnFolds:
         if not items:
             return
         key = tuple(items)
-        table = st["tables"].pop(key, None)
+        table = st["tables"].get(key)
         if table is None:
             import struct
             raw = b"".join(struct.pack("<QQQii", *it) for it in items)
@@ -463,10 +469,12 @@ class _LnFolds:
                 devt = torch.empty(len(raw), dtype=torch.uint8, device=device)
                 devt.copy_(host, non_blocking=True)
             table = (devt, host)
+            if host is not None:
+                # kept for good (a few KB per distinct sequence): a recorded step may replay the upload from
+                # ``host`` into ``devt`` at any later time.  A table in a recorded step's own chunk is not
+                # remembered here: it lives and dies with that step.
+                st["tables"][key] = table
         _StepTables.keep(table)
-        st["tables"][key] = table                # most recently used last
-        while len(st["tables"]) > cls.KEEP:
-            del st["tables"][next(iter(st["tables"]))]
         lib = _lib.load()
         with torch.cuda.device(st["index"]):
             _lib.check(lib.athena_ln_fold_batched(table[0].data_ptr(), len(items), max(it[4] for it in items),

@@ -302,6 +302,14 @@ class _PipelinedGraphStep:
         before = [len(m._pending) for m in metrics_objs]
         torch.cuda.synchronize()
         self.graphs = []
+        with ops.step_tables(self, store.grads.device):
+            self._record_chain(solver, store)
+        self.templates = []
+        for m, n in zip(metrics_objs, before):
+            self.templates.append((m, m._pending[n:]))
+            del m._pending[n:]
+
+    def _record_chain(self, solver, store):
         g0 = torch.cuda.CUDAGraph()
         store.collect_cuts = True
         store.shadows_dirty = True          # the refresh is always part of the recorded forward pass
@@ -337,10 +345,6 @@ class _PipelinedGraphStep:
         with _capture(self.update_graph, g0.pool()):
             solver._update(1.0 / max(solver.world_size, 1))
         self._keep = (cuts, g_mem, g_y, up, g_up)          # the graphs' buffers must outlive them
-        self.templates = []
-        for m, n in zip(metrics_objs, before):
-            self.templates.append((m, m._pending[n:]))
-            del m._pending[n:]
 
     def run(self, samples):
         from .metrics import _Deferred
