@@ -176,7 +176,8 @@ class KernelTimer:
 
 
 GEMM_ENTRIES = ["athena_gemm", "athena_gemm_grouped", "athena_gemm_wgrad_table", "athena_layer_tail_fwd",
-                "athena_layer_tail_bwd", "athena_conv3x3s2_fwd", "athena_conv3x3s2_dgrad", "athena_conv3x3s2_wgrad"]
+                "athena_layer_tail_bwd", "athena_panel_gemm", "athena_panel_gemm_k", "athena_conv3x3s2_fwd",
+                "athena_conv3x3s2_dgrad", "athena_conv3x3s2_wgrad"]
 GEMM_FAMILIES = ("conv2", "layer_gemm", "vocab", "dense_wgrad")
 ATTN_ENTRIES = ["athena_mha_fwd", "athena_mha_bwd"]
 CTC_ENTRIES = ["athena_ctc_loss_fwd", "athena_ctc_loss_bwd", "athena_ctc_loss_fwd_bwd", "athena_rescale_unless"]
@@ -449,7 +450,8 @@ def main():
         flops = sum(fl.values())
         ach = flops * nrep / (g_ms * 1e-3) / 1e12
         roof = {"kernel": "gemm_mfma_kernel / gemm_mfma_grouped_kernel / gemm_big_kernel / gemm_big_table_kernel / "
-                          "layer_tail_*_kernel (+ splitk_reduce): every Dense and implicit-GEMM Conv2D launch of a step",
+                          "layer_tail_*_kernel / panel_*_kernel (+ splitk_reduce): every Dense and implicit-GEMM Conv2D "
+                          "launch of a step",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(args.workload, "gemm"),
                 "launches_per_step": g_launches // nrep, "entry_calls_per_step": g_calls // nrep,

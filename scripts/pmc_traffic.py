@@ -12,7 +12,7 @@ import csv, json, sys
 from collections import defaultdict
 
 FAMILIES = {
-    "gemm": ("gemm_mfma", "gemm_big", "layer_tail", "splitk_reduce"),
+    "gemm": ("gemm_mfma", "gemm_big", "layer_tail", "panel_gemm", "panel_k", "splitk_reduce"),
     "attention": ("mha_",),
     "ctc": ("ctc_", "rescale_unless"),
 }

@@ -25,7 +25,7 @@ def main(path, steps):
         print("%-110s %8d %12.3f %10.2f %10.2f %10.2f %6.2f" % (short(n), cnt, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3,
                                                                   100.0 * s / tot))
     # kernel families as bench.py groups them (C-ABI entry points)
-    fams = [("GEMM cores (gemm_mfma*, gemm_big*, layer_tail*, splitk_reduce*)", ("gemm_mfma", "gemm_big", "layer_tail", "splitk_reduce")),
+    fams = [("GEMM cores (gemm_mfma*, gemm_big*, layer_tail*, panel_*, splitk_reduce*)", ("gemm_mfma", "gemm_big", "layer_tail", "panel_gemm", "panel_k", "splitk_reduce")),
             ("attention (mha_*)", ("mha_",)),
             ("CTC (ctc_*, rescale_unless*)", ("ctc_", "rescale_unless"))]
     print()
