@@ -1,4 +1,5 @@
-"""Times athena_panel_gemm on the benchmark's shapes (8000 rows; 3, 12 and 20 blocks)."""
+"""Times athena_panel_gemm on the benchmark's shapes (ROWS rows, default 8000; 3, 12 and 20 blocks), 20 launches
+back to back in a replayed graph."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,4 +24,4 @@ for nb in (3, 12, 20):
     for _ in range(10):
         g.replay()
     torch.cuda.synchronize()
-    print("dbg %s rows %d blocks %2d: %.1f us" % (os.environ.get("ATHENA_PANEL_DBG", "0"), rows, nb, (time.perf_counter() - t) / 200 * 1e6), flush=True)
+    print("panel_gemm rows %d blocks %2d: %.1f us" % (rows, nb, (time.perf_counter() - t) / 200 * 1e6), flush=True)

@@ -1,3 +1,5 @@
+# Plain step against the forced single-rank data-parallel step, with and without the step-owned tables,
+# alternating on one box (300 steps each, twice); then the model and data-parallel tests.
 set -e
 cd $GRAFT_REPO_ROOT
 B="python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-logit-error"
